@@ -1,0 +1,199 @@
+/*
+ * lpx.h — C ABI of the MI355X-native dense simplex pivot engine (liblpx.so).
+ *
+ * This is the drop-in boundary for ONE path of Toptachamann/Linear_Programming_Solver: the simplex
+ * pivot loop.  The reference has no FFI seam of its own (pure Java); the seam this library sits
+ * behind is the Java API
+ *
+ *     BigDecimal LPSolver.solve(LPStandardForm) throws LPException      (LPSolver.java:78)
+ *     int  LPState.getEntering()                                         (LPState.java:274)
+ *     int  LPState.getLeaving(int entering)                              (LPState.java:287)
+ *     void LPState.pivot(int entering, int leaving)                      (LPState.java:114)
+ *
+ * and every entry point below names the reference member it replaces.  Plain pointers and sizes only;
+ * no torch, no C++ types.  A JNI / ctypes binding over these symbols is shown in INTEGRATION.md.
+ *
+ * Data model (reference LPState.java:25-30, "condensed" CLRS slack form):
+ *   A   m x n row-major fp64, A[i][j] = coefficient of the variable in nonbasic SLOT j in the equation
+ *       of the basic variable of row i:   x_basic(i) = b[i] - sum_j A[i][j] * x_slot(j)
+ *   b   m, c n, scalar v (objective constant).  Maximisation sign convention (c[j] > 0 improves).
+ *   perm int32[n+m]: slot -> variable id.  Slots 0..n-1 are nonbasic, slot n+i is the basic variable
+ *       of row i.  Ids 0..n-1 are the caller's original variables, n..n+m-1 the slacks of rows 0..m-1
+ *       (this replaces the reference's two HashMaps `variables` / `coefficients`, LPState.java:27-28,
+ *       swapped by exchangeIndexes, :311-320).
+ * Arithmetic is IEEE fp64, one rounding per reference operation, never fused: t = ce*row[j]; a - t
+ * (the reference rounds the product and the difference separately, LPState.java:162).
+ *
+ * Threading: a handle is single-caller (the reference classes are not thread-safe either); different
+ * handles may be driven from different host threads.  All device work of a handle is issued on one HIP
+ * stream (lpx_state_set_stream); calls that return values to the host synchronise that stream.
+ */
+#ifndef LPX_H
+#define LPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPX_ABI_VERSION 1
+
+/* Status codes.  One per exception message of the reference; the host shim maps them back
+ * to the exact exception class + message because the reference's tests assert on the text. */
+typedef enum lpx_status {
+  LPX_OPTIMAL = 0,             /* getEntering() == -1: loop finished                 LPSolver.java:101      */
+  LPX_UNBOUNDED = 1,           /* SolutionException "This linear program is unbounded"          :103-106    */
+  LPX_INFEASIBLE = 2,          /* LPException "This linear program is infeasible"               :171-174    */
+  LPX_AUX_UNBOUNDED = 3,       /* SolutionException "Auxiliary lp is unbounded"                 :147-150    */
+  LPX_NO_DEGENERATE_PIVOT = 4, /* SolutionException "Can't perform degenerate pivot"            :192-194    */
+  LPX_BAD_ARGUMENT = 5,        /* IllegalArgumentException (Validate.isTrue)             LPState.java:288   */
+  LPX_RESTORE_INDEX_FAULT = 6, /* ArrayIndexOutOfBoundsException in restoreInitialLP     LPSolver.java:231  */
+  LPX_DEVICE_ERROR = 7,        /* HIP runtime error (no reference analogue)                                 */
+  LPX_DIVIDE_BY_ZERO = 8,      /* ArithmeticException: pivot on a zero element           LPState.java:139   */
+  LPX_PIVOT_LIMIT = 9          /* max_pivots reached, loop still running (no reference analogue)            */
+} lpx_status;
+
+/* Exact reference exception text for a status ("" for OPTIMAL / PIVOT_LIMIT). Never NULL. */
+const char* lpx_status_message(int status);
+/* Last error text of the calling thread (HIP error string, argument complaint). Never NULL. */
+const char* lpx_last_error(void);
+int lpx_abi_version(void);
+/* Number of HIP devices visible; <0 on error. */
+int lpx_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * LPState: device-resident slack-form tableau + the three simplex primitives.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lpx_state lpx_state;
+
+/* new LPState(A, b, c, v, variables, coefficients, m, n)              LPState.java:88-112
+ * Copies the host arrays into HBM on `device` (the reference aliases the caller's arrays,
+ * LPSolver.java:267; this library never writes caller memory except in the read-back calls).
+ * A is row-major with leading dimension lda >= n (elements).  perm may be NULL: identity.
+ * Row-block shard form (multi-GPU): this handle owns global rows
+ * [row0, row0 + m_local) of an m_global-row tableau; pass row0 = 0, m_global = m_local for one GPU.
+ * b has m_local entries (the shard's rows); c, v and perm (n + m_global entries) are replicated. */
+int lpx_state_create(int32_t m_local, int32_t n, const double* A, int64_t lda, const double* b,
+                     const double* c, double v, const int32_t* perm, int32_t row0, int32_t m_global,
+                     int device, lpx_state** out);
+/* Same, but A/b/c are DEVICE pointers already resident in HBM on `device` (copied device-to-device). */
+int lpx_state_create_from_device(int32_t m_local, int32_t n, const double* dA, int64_t lda,
+                                 const double* db, const double* dc, double v, const int32_t* perm,
+                                 int32_t row0, int32_t m_global, int device, lpx_state** out);
+void lpx_state_destroy(lpx_state* s);
+/* Issue all further device work of this handle on `hip_stream` (a hipStream_t; NULL = the handle's own). */
+int lpx_state_set_stream(lpx_state* s, void* hip_stream);
+
+/* int getEntering()                                                    LPState.java:274-285
+ * *entering = min{ j in [0,n) : c[j] > 1e-9 } or -1. */
+int lpx_get_entering(lpx_state* s, int32_t* entering);
+/* int getLeaving(int entering)                                         LPState.java:287-305
+ * ratio_i = (A[i][e] < 1e-9) ? 1e50 : b[i]/A[i][e]; strict '<' scan from 1e50: lowest row wins ties;
+ * *leaving = -1 if no ratio is below 1e50.  entering outside [0,n) -> LPX_BAD_ARGUMENT.
+ * On a shard the result is the shard-local candidate (global row index) and *ratio its ratio. */
+int lpx_get_leaving(lpx_state* s, int32_t entering, int32_t* leaving, double* ratio);
+/* void pivot(int entering, int leaving)                                LPState.java:114-181, :311-320
+ * Pivot row normalise, rank-1 update of all other rows and of b, objective row and v update,
+ * slot/basis swap in perm.  `leaving` is a row index in [0,m).  A zero pivot element returns
+ * LPX_DIVIDE_BY_ZERO and leaves the state untouched.  Single-GPU handles only. */
+int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving);
+
+/* The loop of LPSolver.simplex                                         LPSolver.java:101-107
+ * while ((e = getEntering()) != -1) { l = getLeaving(e); if (l == -1) unbounded; pivot(e, l); }
+ * run device-resident (no host decision per pivot) for at most max_pivots pivots (<0: unlimited).
+ * *status = LPX_OPTIMAL | LPX_UNBOUNDED | LPX_PIVOT_LIMIT.  track_slot >= 0 follows one variable's slot
+ * through the pivots exactly as solveAuxLP does for x0 (LPSolver.java:151-155); the updated slot is
+ * written back to *track_slot.  Pass NULL to track nothing. */
+int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivots_done, int32_t* status,
+                     int32_t* track_slot);
+
+/* Read-back (host pointers; any may be NULL).  A is written row-major with leading dimension lda. */
+int lpx_state_read(lpx_state* s, double* A, int64_t lda, double* b, double* c, double* v,
+                   int32_t* perm);
+int lpx_state_dims(const lpx_state* s, int32_t* m_local, int32_t* n, int32_t* row0, int32_t* m_global);
+/* Order-independent 64-bit checksums of the bit patterns of A (xor/sum of per-element hashes keyed by
+ * position), b and c, computed on the device: lets full-size parity tests compare tableaux without a
+ * 1 GiB read-back.  out[0..2] = A, b, c. */
+int lpx_state_checksum(lpx_state* s, uint64_t out[3]);
+
+/* Per-kernel timing of the row-update kernel with HIP events on the handle's stream (bench.py's
+ * roofline figure).  enable=1 starts collecting; lpx_profile_read returns launches and total ms since
+ * enable and resets the counters. */
+int lpx_profile_enable(lpx_state* s, int enable);
+int lpx_profile_read(lpx_state* s, int64_t* launches, double* total_ms);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-block shards (one process per GPU; the exchange itself is done by the host with
+ * torch.distributed / RCCL between these two calls).
+ * Candidate record, LPX_CAND_HEADER + n doubles:
+ *   [0] status flag (0 running, else an lpx_status + 1 decided from the replicated c)
+ *   [1] entering slot e        [2] local best ratio (1e50 if none)   [3] its GLOBAL row (-1 if none)
+ *   [4] b[row] (un-normalised) [5..7] reserved
+ *   [8 .. 8+n) the un-normalised candidate pivot row A[row][0..n)
+ * ---------------------------------------------------------------------------------------------- */
+#define LPX_CAND_HEADER 8
+/* Phase A: entering scan on the replicated c, local ratio test on the shard's slice of column e, pack the
+ * shard's candidate into d_candidate (DEVICE pointer, LPX_CAND_HEADER + n doubles).  No host sync. */
+int lpx_shard_propose(lpx_state* s, double* d_candidate);
+/* Phase B: d_gathered holds nranks candidate records back to back (DEVICE pointer, all-gathered).
+ * Every rank picks the same winner (min ratio, lowest global row), normalises the pivot row, updates its
+ * replicas of c, v, perm and runs the row update on its own block.  No host sync. */
+int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t nranks);
+/* Host poll of the replicated loop state: pivots done so far and LPX_OPTIMAL / LPX_UNBOUNDED /
+ * LPX_PIVOT_LIMIT (= still running).  Synchronises the stream. */
+int lpx_shard_poll(lpx_state* s, int64_t* pivots_done, int32_t* status);
+
+/* ------------------------------------------------------------------------------------------------
+ * LPSolver.solve                                                       LPSolver.java:78-94
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lpx_solve_result {
+  int32_t status;          /* lpx_status */
+  int32_t phase1_used;     /* 1 if the auxiliary LP was needed (min b < 0)          LPSolver.java:119-131 */
+  double objective;        /* unrounded LPState.v, sign-corrected for minimisation                        */
+  double objective_rounded;/* v.setScale(6, HALF_UP) as the nearest double           LPSolver.java:113    */
+  char objective_text[64]; /* the same as decimal text with 6 fractional digits ("8.000000")              */
+  int64_t pivots_phase1;   /* incl. the forced first pivot and the degenerate pivot  LPSolver.java:138,195 */
+  int64_t pivots_phase2;
+  int32_t x0_slot;         /* final aux-LP slot of x0 (-1 if phase 1 unused)         LPSolver.java:162    */
+  int32_t reserved;
+  double seconds_total;    /* wall time inside lpx_solve, upload included                                 */
+  double seconds_pivots;   /* wall time of the device pivot loops only                                    */
+} lpx_solve_result;
+
+typedef struct lpx_solve_options {
+  int32_t device;               /* HIP device ordinal                                                     */
+  int32_t has_variable_names;   /* LPStandardForm.hasVariableNames(); only affects nothing numerically,   */
+                                /* kept for shim symmetry                                                 */
+  int64_t max_pivots;           /* <0: unlimited (the reference has no limit)                             */
+  const int32_t* restore_order; /* iteration order of initial.coefficients.keySet() in restoreInitialLP   */
+                                /* (LPSolver.java:213-217) as original-variable indices; NULL = the order */
+                                /* java.util.HashMap gives the default names "x1".."xn" (:388-400)        */
+  int32_t* perm_out;            /* optional int32[n+m]: final slot -> variable id                         */
+  double* x_out;                /* optional double[n]: primal solution (basic slot -> b[i], else 0)       */
+  lpx_state** keep_state;       /* optional: receive the final LPState handle instead of destroying it    */
+} lpx_solve_options;
+
+/* BigDecimal LPSolver.solve(LPStandardForm stForm)                      LPSolver.java:78
+ * A (lda), b, c are HOST arrays of the standard form  max/min c.x  s.t.  A x <= b, x >= 0
+ * (LPStandardForm.java:11-16).  Unlike the reference, the caller's arrays are never modified (the
+ * reference negates stForm.c in place for `min`, :86-89, and pivots inside stForm.A/b/c, :267).
+ * Returns LPX_OPTIMAL (0) or the status that the reference would have thrown as an exception;
+ * result->status carries the same code. */
+int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, const double* b, const double* c,
+              int32_t maximize, const lpx_solve_options* opts, lpx_solve_result* result);
+
+/* Iteration order of a java.util.HashMap<String,Integer> filled by put("x1"), put("x2"), ... put("xn")
+ * into a default-constructed map (LPSolver.addDefaultVariables, LPSolver.java:388-400): writes the
+ * 0-based variable indices in keySet() order.  Host-only helper (no device work). */
+int lpx_java_default_name_order(int32_t n, int32_t* order_out);
+
+/* LPStandardForm.getDual()                                              LPStandardForm.java:129-152
+ * Device transpose: At (n x m, leading dimension ldat) = transpose of A (m x n, lda).  HOST pointers. */
+int lpx_transpose(int32_t m, int32_t n, const double* A, int64_t lda, double* At, int64_t ldat, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPX_H */
