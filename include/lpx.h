@@ -134,6 +134,10 @@ int lpx_profile_read(lpx_state* s, int64_t* launches, double* total_ms);
  *   [8 .. 8+n) the un-normalised candidate pivot row A[row][0..n)
  * ---------------------------------------------------------------------------------------------- */
 #define LPX_CAND_HEADER 8
+/* Start (or restart) a sharded loop: reset the replicated loop state (pivot budget, tracked slot as in
+ * lpx_simplex_loop), run the entering scan on the replicated c and seed this shard's pivot column and
+ * ratio partials.  Every rank calls it with the same arguments.  No host sync. */
+int lpx_shard_begin(lpx_state* s, int64_t max_pivots, int32_t track_slot);
 /* Phase A: entering scan on the replicated c, local ratio test on the shard's slice of column e, pack the
  * shard's candidate into d_candidate (DEVICE pointer, LPX_CAND_HEADER + n doubles).  No host sync. */
 int lpx_shard_propose(lpx_state* s, double* d_candidate);

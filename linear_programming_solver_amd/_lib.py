@@ -1,0 +1,106 @@
+"""ctypes binding of liblpx.so (include/lpx.h).  The product path has NO CPU fallback: if the HIP library
+is missing or cannot be loaded this module raises, loudly, at first use."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblpx.so")
+
+# lpx_status (include/lpx.h)
+OPTIMAL, UNBOUNDED, INFEASIBLE, AUX_UNBOUNDED, NO_DEGENERATE_PIVOT, BAD_ARGUMENT, RESTORE_INDEX_FAULT, \
+    DEVICE_ERROR, DIVIDE_BY_ZERO, PIVOT_LIMIT = range(10)
+CAND_HEADER = 8
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+
+
+class SolveResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32),
+        ("phase1_used", C.c_int32),
+        ("objective", C.c_double),
+        ("objective_rounded", C.c_double),
+        ("objective_text", C.c_char * 64),
+        ("pivots_phase1", C.c_int64),
+        ("pivots_phase2", C.c_int64),
+        ("x0_slot", C.c_int32),
+        ("reserved", C.c_int32),
+        ("seconds_total", C.c_double),
+        ("seconds_pivots", C.c_double),
+    ]
+
+
+class SolveOptions(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("has_variable_names", C.c_int32),
+        ("max_pivots", C.c_int64),
+        ("restore_order", ip),
+        ("perm_out", ip),
+        ("x_out", dp),
+        ("keep_state", C.POINTER(C.c_void_p)),
+    ]
+
+
+# every symbol include/lpx.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("lpx_status_message", C.c_char_p, [C.c_int]),
+    ("lpx_last_error", C.c_char_p, []),
+    ("lpx_abi_version", C.c_int, []),
+    ("lpx_device_count", C.c_int, []),
+    ("lpx_state_create", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_double, ip, C.c_int32,
+                                   C.c_int32, C.c_int, C.POINTER(C.c_void_p)]),
+    ("lpx_state_create_from_device", C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_void_p, C.c_double, ip, C.c_int32, C.c_int32, C.c_int,
+                                               C.POINTER(C.c_void_p)]),
+    ("lpx_state_destroy", None, [C.c_void_p]),
+    ("lpx_state_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("lpx_get_entering", C.c_int, [C.c_void_p, ip]),
+    ("lpx_get_leaving", C.c_int, [C.c_void_p, C.c_int32, ip, dp]),
+    ("lpx_pivot", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("lpx_simplex_loop", C.c_int, [C.c_void_p, C.c_int64, i64p, ip, ip]),
+    ("lpx_state_read", C.c_int, [C.c_void_p, dp, C.c_int64, dp, dp, dp, ip]),
+    ("lpx_state_dims", C.c_int, [C.c_void_p, ip, ip, ip, ip]),
+    ("lpx_state_checksum", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("lpx_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("lpx_profile_read", C.c_int, [C.c_void_p, i64p, dp]),
+    ("lpx_shard_begin", C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
+    ("lpx_shard_propose", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("lpx_shard_commit", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    ("lpx_shard_poll", C.c_int, [C.c_void_p, i64p, ip]),
+    ("lpx_solve", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(SolveOptions),
+                            C.POINTER(SolveResult)]),
+    ("lpx_java_default_name_order", C.c_int, [C.c_int32, ip]),
+    ("lpx_transpose", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, C.c_int64, C.c_int]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load liblpx.so and bind every declared symbol; raises if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "liblpx.so (the HIP extension) is missing at %s: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C linear_programming_solver_amd/csrc`. "
+            "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().lpx_last_error().decode()
+
+
+def status_message(status):
+    return lib().lpx_status_message(int(status)).decode()

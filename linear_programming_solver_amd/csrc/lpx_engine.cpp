@@ -1,0 +1,554 @@
+// Host engine behind include/lpx.h: owns the device-resident LPState, issues the pivot kernels on one HIP
+// stream and polls the device loop state.  No decision about a pivot is ever taken on the host inside the
+// loop: the host enqueues (select_pivot, update) pairs ahead of the GPU and reads LpxCtl::status from
+// pinned memory once per batch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lpx.h"
+#include "lpx_kernels.h"
+
+using lpxk::Buffers;
+using lpxk::Geometry;
+using lpxk::LpxCtl;
+using lpxk::RatioRow;
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+static int fail(int status, const std::string& msg) {
+  g_last_error = msg;
+  return status;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail(LPX_DEVICE_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+  } while (0)
+
+extern "C" const char* lpx_status_message(int status) {
+  switch (status) {
+    case LPX_UNBOUNDED: return "This linear program is unbounded";                 // LPSolver.java:105
+    case LPX_INFEASIBLE: return "This linear program is infeasible";               // LPSolver.java:173
+    case LPX_AUX_UNBOUNDED: return "Auxiliary lp is unbounded";                    // LPSolver.java:149
+    case LPX_NO_DEGENERATE_PIVOT: return "Can't perform degenerate pivot";         // LPSolver.java:193
+    case LPX_BAD_ARGUMENT: return "IllegalArgumentException";                      // LPState.java:288
+    case LPX_RESTORE_INDEX_FAULT: return "ArrayIndexOutOfBoundsException";         // LPSolver.java:231
+    case LPX_DEVICE_ERROR: return "HIP device error";
+    case LPX_DIVIDE_BY_ZERO: return "Division by zero";                            // LPState.java:139
+    default: return "";
+  }
+}
+
+extern "C" const char* lpx_last_error(void) { return g_last_error.c_str(); }
+extern "C" int lpx_abi_version(void) { return LPX_ABI_VERSION; }
+
+extern "C" int lpx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------ state
+struct lpx_state {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  int32_t m = 0;         // local rows
+  int32_t n = 0;         // nonbasic slots (columns in use)
+  int32_t row0 = 0, m_global = 0;
+  int32_t n_cap = 0;     // n the buffers were sized for (phase 1 allocates n+1 and later shrinks n)
+  Buffers B{};
+  Geometry g{};
+  bool nontemporal = false;
+  LpxCtl* h_ctl = nullptr;          // pinned mirror
+  unsigned long long* d_sum = nullptr;
+  // row-update profiling (HIP events on `stream`)
+  bool prof = false;
+  std::vector<hipEvent_t> ev;       // pairs
+  size_t ev_used = 0;
+  int64_t prof_launches = 0;
+  double prof_ms = 0.0;
+};
+
+static int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+
+static int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+// Tiling of k_update: enough workgroups to fill 256 CUs several times over, strips as wide as the row
+// allows so the pivot-row slice a workgroup keeps in registers is amortised over rows_per_tile rows.
+static Geometry choose_geometry(int m, int64_t ld) {
+  Geometry g{};
+  int U = ld >= 8192 ? 4 : (ld >= 2048 ? 2 : 1);
+  U = env_int("LPX_U", U);
+  if (U != 1 && U != 2 && U != 4) U = 4;
+  g.U = U;
+  const int W = 512 * U;
+  g.nstrips = (int)((ld + W - 1) / W);
+  const int target_blocks = env_int("LPX_TARGET_BLOCKS", 2048);
+  int64_t R = ((int64_t)m * g.nstrips + target_blocks - 1) / target_blocks;
+  R = std::max<int64_t>(2, std::min<int64_t>(64, R));
+  if (R & 1) R += 1;  // rows are processed in pairs
+  R = env_int("LPX_ROWS_PER_TILE", (int)R);
+  g.rows_per_tile = (int)R;
+  g.ntiles = m > 0 ? (int)((m + R - 1) / R) : 0;
+  return g;
+}
+
+static int sync_ctl_to_host(lpx_state* s) {
+  HIP_TRY(hipMemcpyAsync(s->h_ctl, s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+static int push_ctl(lpx_state* s) {
+  HIP_TRY(hipMemcpyAsync(s->B.ctl, s->h_ctl, sizeof(LpxCtl), hipMemcpyHostToDevice, s->stream));
+  return 0;
+}
+
+static void free_state(lpx_state* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+  (void)hipFree(s->B.A);
+  (void)hipFree(s->B.b);
+  (void)hipFree(s->B.c);
+  (void)hipFree(s->B.prow);
+  (void)hipFree(s->B.col[0]);
+  (void)hipFree(s->B.col[1]);
+  (void)hipFree(s->B.partial);
+  (void)hipFree(s->B.perm);
+  (void)hipFree(s->B.ctl);
+  (void)hipFree(s->d_sum);
+  if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+  if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+  delete s;
+}
+
+// Allocates buffers for an m_local x n_cap tableau (n columns in use) and zero-fills the padding.
+static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t m_global, int device,
+                       lpx_state** out) {
+  if (m_local < 0 || n < 0 || n_cap < n || row0 < 0 || m_global < m_local || row0 + m_local > m_global)
+    return fail(LPX_BAD_ARGUMENT, "lpx_state_create: bad dimensions");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(LPX_BAD_ARGUMENT, "lpx_state_create: no such device");
+  HIP_TRY(hipSetDevice(device));
+  lpx_state* s = new lpx_state();
+  s->device = device;
+  s->m = m_local; s->n = n; s->n_cap = n_cap; s->row0 = row0; s->m_global = m_global;
+  const int64_t ld = std::max<int64_t>(16, round_up(n_cap, 16));
+  const int64_t mp = std::max<int64_t>(2, round_up(m_local, 2)) + 2;
+  s->B.ld = ld;
+  s->g = choose_geometry(m_local, ld);
+  // non-temporal streaming only pays once the tableau no longer fits the 256 MiB Infinity Cache
+  const int64_t bytes = (int64_t)m_local * ld * 8;
+  s->nontemporal = env_int("LPX_NT", bytes > (192ll << 20) ? 1 : 0) != 0;
+#define ALLOC(ptr, count, type)                                                            \
+  do {                                                                                     \
+    hipError_t _e = hipMalloc((void**)&(ptr), std::max<size_t>(1, (size_t)(count)) * sizeof(type)); \
+    if (_e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, std::string("hipMalloc: ") + hipGetErrorString(_e)); } \
+    _e = hipMemset((ptr), 0, std::max<size_t>(1, (size_t)(count)) * sizeof(type));          \
+    if (_e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, std::string("hipMemset: ") + hipGetErrorString(_e)); } \
+  } while (0)
+  ALLOC(s->B.A, mp * ld, double);
+  ALLOC(s->B.b, mp, double);
+  ALLOC(s->B.c, ld, double);
+  ALLOC(s->B.prow, ld, double);
+  ALLOC(s->B.col[0], mp, double);
+  ALLOC(s->B.col[1], mp, double);
+  ALLOC(s->B.partial, std::max(1, s->g.ntiles), RatioRow);
+  ALLOC(s->B.perm, (int64_t)n_cap + m_global, int32_t);
+  ALLOC(s->B.ctl, 1, LpxCtl);
+  ALLOC(s->d_sum, 4, unsigned long long);
+#undef ALLOC
+  hipError_t e = hipHostMalloc((void**)&s->h_ctl, sizeof(LpxCtl), hipHostMallocDefault);
+  if (e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, "hipHostMalloc failed"); }
+  memset(s->h_ctl, 0, sizeof(LpxCtl));
+  e = hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, "hipStreamCreate failed"); }
+  s->stream = s->own_stream;
+  HIP_TRY(hipDeviceSynchronize());  // the memsets above ran on the null stream
+  *out = s;
+  return 0;
+}
+
+static void init_ctl(lpx_state* s, double v) {
+  LpxCtl& c = *s->h_ctl;
+  memset(&c, 0, sizeof c);
+  c.v = v;
+  c.e_next = -1; c.e_cur = -1; c.l = -1;
+  c.status = lpxk::kRunning;
+  c.track = -1;
+  c.max_pivots = -1;
+}
+
+static int upload_common(lpx_state* s, const double* A, int64_t lda, const double* b, const double* c, double v,
+                         const int32_t* perm, hipMemcpyKind kind) {
+  const int32_t m = s->m, n = s->n;
+  if (m > 0 && n > 0) {
+    if (lda < n) return fail(LPX_BAD_ARGUMENT, "lpx_state_create: lda < n");
+    HIP_TRY(hipMemcpy2DAsync(s->B.A, s->B.ld * sizeof(double), A, lda * sizeof(double), (size_t)n * sizeof(double),
+                             (size_t)m, kind, s->stream));
+  }
+  if (m > 0) HIP_TRY(hipMemcpyAsync(s->B.b, b, (size_t)m * sizeof(double), kind, s->stream));
+  if (n > 0) HIP_TRY(hipMemcpyAsync(s->B.c, c, (size_t)n * sizeof(double), kind, s->stream));
+  std::vector<int32_t> p((size_t)n + s->m_global);
+  for (size_t i = 0; i < p.size(); i++) p[i] = perm ? perm[i] : (int32_t)i;
+  if (!p.empty())
+    HIP_TRY(hipMemcpyAsync(s->B.perm, p.data(), p.size() * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+  init_ctl(s, v);
+  if (int rc = push_ctl(s)) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+
+extern "C" int lpx_state_create(int32_t m_local, int32_t n, const double* A, int64_t lda, const double* b,
+                                const double* c, double v, const int32_t* perm, int32_t row0, int32_t m_global,
+                                int device, lpx_state** out) {
+  if (!out) return fail(LPX_BAD_ARGUMENT, "lpx_state_create: out is NULL");
+  *out = nullptr;
+  if ((m_local > 0 && n > 0 && !A) || (m_local > 0 && !b) || (n > 0 && !c))
+    return fail(LPX_BAD_ARGUMENT, "lpx_state_create: NULL array");
+  lpx_state* s = nullptr;
+  if (int rc = alloc_state(m_local, n, n, row0, m_global, device, &s)) return rc;
+  if (int rc = upload_common(s, A, lda, b, c, v, perm, hipMemcpyHostToDevice)) { free_state(s); return rc; }
+  *out = s;
+  return 0;
+}
+
+extern "C" int lpx_state_create_from_device(int32_t m_local, int32_t n, const double* dA, int64_t lda,
+                                            const double* db, const double* dc, double v, const int32_t* perm,
+                                            int32_t row0, int32_t m_global, int device, lpx_state** out) {
+  if (!out) return fail(LPX_BAD_ARGUMENT, "lpx_state_create_from_device: out is NULL");
+  *out = nullptr;
+  if ((m_local > 0 && n > 0 && !dA) || (m_local > 0 && !db) || (n > 0 && !dc))
+    return fail(LPX_BAD_ARGUMENT, "lpx_state_create_from_device: NULL array");
+  lpx_state* s = nullptr;
+  if (int rc = alloc_state(m_local, n, n, row0, m_global, device, &s)) return rc;
+  if (int rc = upload_common(s, dA, lda, db, dc, v, perm, hipMemcpyDeviceToDevice)) { free_state(s); return rc; }
+  *out = s;
+  return 0;
+}
+
+extern "C" void lpx_state_destroy(lpx_state* s) { free_state(s); }
+
+extern "C" int lpx_state_set_stream(lpx_state* s, void* hip_stream) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, "NULL state");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  s->stream = hip_stream ? (hipStream_t)hip_stream : s->own_stream;
+  return 0;
+}
+
+extern "C" int lpx_state_dims(const lpx_state* s, int32_t* m_local, int32_t* n, int32_t* row0, int32_t* m_global) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, "NULL state");
+  if (m_local) *m_local = s->m;
+  if (n) *n = s->n;
+  if (row0) *row0 = s->row0;
+  if (m_global) *m_global = s->m_global;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ launches
+static int launch_update_profiled(lpx_state* s) {
+  if (s->prof) {
+    if (s->ev_used + 2 > s->ev.size()) {
+      for (int k = 0; k < 512; k++) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->ev.push_back(e);
+      }
+    }
+    HIP_TRY(hipEventRecord(s->ev[s->ev_used], s->stream));
+    lpxk::launch_update(s->B, s->m, s->n, s->row0, s->g, s->nontemporal, s->stream);
+    HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], s->stream));
+    s->ev_used += 2;
+  } else {
+    lpxk::launch_update(s->B, s->m, s->n, s->row0, s->g, s->nontemporal, s->stream);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int drain_profile(lpx_state* s) {
+  if (s->ev_used == 0) return 0;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  for (size_t k = 0; k + 1 < s->ev_used; k += 2) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev[k], s->ev[k + 1]));
+    s->prof_ms += ms;
+    s->prof_launches += 1;
+  }
+  s->ev_used = 0;
+  return 0;
+}
+
+extern "C" int lpx_profile_enable(lpx_state* s, int enable) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, "NULL state");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = drain_profile(s)) return rc;
+  s->prof = enable != 0;
+  s->prof_launches = 0;
+  s->prof_ms = 0.0;
+  return 0;
+}
+
+extern "C" int lpx_profile_read(lpx_state* s, int64_t* launches, double* total_ms) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, "NULL state");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = drain_profile(s)) return rc;
+  if (launches) *launches = s->prof_launches;
+  if (total_ms) *total_ms = s->prof_ms;
+  s->prof_launches = 0;
+  s->prof_ms = 0.0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ step API
+static int require_single(lpx_state* s, const char* who) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, std::string(who) + ": NULL state");
+  if (s->row0 != 0 || s->m_global != s->m)
+    return fail(LPX_BAD_ARGUMENT, std::string(who) + ": not available on a row-block shard");
+  return 0;
+}
+
+static int set_running(lpx_state* s, int64_t max_pivots, int32_t track) {
+  if (int rc = sync_ctl_to_host(s)) return rc;
+  s->h_ctl->status = lpxk::kRunning;
+  s->h_ctl->do_update = 0;
+  s->h_ctl->pivots = 0;
+  s->h_ctl->max_pivots = max_pivots;
+  s->h_ctl->track = track;
+  return push_ctl(s);
+}
+
+extern "C" int lpx_get_entering(lpx_state* s, int32_t* entering) {
+  if (!s || !entering) return fail(LPX_BAD_ARGUMENT, "lpx_get_entering: NULL argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = set_running(s, -1, -1)) return rc;
+  lpxk::launch_entering(s->B, s->n, s->stream);
+  HIP_TRY(hipGetLastError());
+  if (int rc = sync_ctl_to_host(s)) return rc;
+  *entering = s->h_ctl->e_next;
+  return 0;
+}
+
+extern "C" int lpx_get_leaving(lpx_state* s, int32_t entering, int32_t* leaving, double* ratio) {
+  if (!s || !leaving) return fail(LPX_BAD_ARGUMENT, "lpx_get_leaving: NULL argument");
+  if (!(entering >= 0 && entering < s->n))  // Validate.isTrue, LPState.java:288
+    return fail(LPX_BAD_ARGUMENT, "lpx_get_leaving: entering outside [0, n)");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = set_running(s, -1, -1)) return rc;
+  lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, entering, s->stream);
+  lpxk::launch_reduce_partials(s->B, s->g, s->stream);
+  HIP_TRY(hipGetLastError());
+  if (int rc = sync_ctl_to_host(s)) return rc;
+  *leaving = s->h_ctl->l;
+  if (ratio) *ratio = s->h_ctl->ratio;
+  return 0;
+}
+
+extern "C" int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving) {
+  if (int rc = require_single(s, "lpx_pivot")) return rc;
+  if (!(entering >= 0 && entering < s->n) || !(leaving >= 0 && leaving < s->m))
+    return fail(LPX_BAD_ARGUMENT, "lpx_pivot: index out of range");  // ArrayIndexOutOfBounds in the reference
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = set_running(s, -1, -1)) return rc;
+  lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, entering, s->stream);  // column `entering` -> col[parity]
+  lpxk::launch_select_pivot(s->B, s->n, s->m_global, s->g, entering, leaving, s->stream);
+  if (int rc = launch_update_profiled(s)) return rc;
+  HIP_TRY(hipGetLastError());
+  if (int rc = sync_ctl_to_host(s)) return rc;
+  if (s->h_ctl->status == LPX_DIVIDE_BY_ZERO) return fail(LPX_DIVIDE_BY_ZERO, "lpx_pivot: pivot element is zero");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ the loop
+extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivots_done, int32_t* status,
+                                int32_t* track_slot) {
+  if (int rc = require_single(s, "lpx_simplex_loop")) return rc;
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = set_running(s, max_pivots, track_slot ? *track_slot : -1)) return rc;
+  // seed: entering scan + strided column gather / partials for the first pivot
+  lpxk::launch_entering(s->B, s->n, s->stream);
+  lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, -1, s->stream);
+  HIP_TRY(hipGetLastError());
+
+  // batch size: ~1-2 ms of GPU work between host polls
+  const double est_us = 16.0 * (double)s->m * (double)s->B.ld / 4.0e6 + 12.0;
+  int batch = (int)std::max(1.0, std::min(256.0, 1500.0 / est_us));
+  batch = env_int("LPX_BATCH", batch);
+
+  hipEvent_t evs[2];
+  HIP_TRY(hipEventCreateWithFlags(&evs[0], hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&evs[1], hipEventDisableTiming));
+  LpxCtl* h2 = nullptr;  // two pinned snapshots so that batch k+1 can be in flight while k is inspected
+  HIP_TRY(hipHostMalloc((void**)&h2, 2 * sizeof(LpxCtl), hipHostMallocDefault));
+
+  int64_t enqueued = 0;  // select/update pairs issued
+  auto issue_batch = [&](int slot) -> int {
+    int nb = batch;
+    if (max_pivots >= 0) {
+      // never issue more pairs than the budget allows (+1 so that the LIMIT status itself is reached)
+      const int64_t room = max_pivots + 1 - enqueued;
+      nb = (int)std::max<int64_t>(0, std::min<int64_t>(nb, room));
+    }
+    for (int k = 0; k < nb; k++) {
+      lpxk::launch_select_pivot(s->B, s->n, s->m_global, s->g, -1, -1, s->stream);
+      if (k == nb - 1 && max_pivots >= 0 && enqueued + k + 1 == max_pivots + 1) break;  // last one only reports LIMIT
+      if (int rc = launch_update_profiled(s)) return rc;
+    }
+    enqueued += nb;
+    HIP_TRY(hipMemcpyAsync(&h2[slot], s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(evs[slot], s->stream));
+    return 0;
+  };
+
+  int rc = issue_batch(0);
+  int cur = 0;
+  int result = 0;
+  while (rc == 0) {
+    rc = issue_batch(cur ^ 1);
+    if (rc) break;
+    hipError_t e = hipEventSynchronize(evs[cur]);
+    if (e != hipSuccess) { rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e)); break; }
+    if (h2[cur].status != lpxk::kRunning) break;
+    cur ^= 1;
+  }
+  hipError_t e2 = hipStreamSynchronize(s->stream);
+  if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
+  (void)hipEventDestroy(evs[0]);
+  (void)hipEventDestroy(evs[1]);
+  (void)hipHostFree(h2);
+  if (rc) return rc;
+  if (int r2 = sync_ctl_to_host(s)) return r2;
+  if (pivots_done) *pivots_done = s->h_ctl->pivots;
+  if (status) *status = s->h_ctl->status;
+  if (track_slot) *track_slot = s->h_ctl->track;
+  if (s->h_ctl->status == LPX_DIVIDE_BY_ZERO) result = fail(LPX_DIVIDE_BY_ZERO, "pivot element is zero");
+  return result;
+}
+
+// ------------------------------------------------------------------------------------------------ shards
+extern "C" int lpx_shard_propose(lpx_state* s, double* d_candidate) {
+  if (!s || !d_candidate) return fail(LPX_BAD_ARGUMENT, "lpx_shard_propose: NULL argument");
+  HIP_TRY(hipSetDevice(s->device));
+  lpxk::launch_propose(s->B, s->n, s->row0, s->m, s->g, d_candidate, s->stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t nranks) {
+  if (!s || !d_gathered || nranks < 1) return fail(LPX_BAD_ARGUMENT, "lpx_shard_commit: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, s->stream);
+  if (int rc = launch_update_profiled(s)) return rc;
+  return 0;
+}
+
+// Starts (or restarts) a sharded loop: resets the replicated loop state and seeds column/partials.
+extern "C" int lpx_shard_begin(lpx_state* s, int64_t max_pivots, int32_t track_slot) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, "lpx_shard_begin: NULL state");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = set_running(s, max_pivots, track_slot)) return rc;
+  lpxk::launch_entering(s->B, s->n, s->stream);
+  lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, -1, s->stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int lpx_shard_poll(lpx_state* s, int64_t* pivots_done, int32_t* status) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, "lpx_shard_poll: NULL state");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = sync_ctl_to_host(s)) return rc;
+  if (pivots_done) *pivots_done = s->h_ctl->pivots;
+  if (status) *status = s->h_ctl->status == lpxk::kRunning ? (int32_t)LPX_PIVOT_LIMIT : s->h_ctl->status;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ read-back
+extern "C" int lpx_state_read(lpx_state* s, double* A, int64_t lda, double* b, double* c, double* v, int32_t* perm) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, "NULL state");
+  HIP_TRY(hipSetDevice(s->device));
+  if (A && s->m > 0 && s->n > 0) {
+    if (lda < s->n) return fail(LPX_BAD_ARGUMENT, "lpx_state_read: lda < n");
+    HIP_TRY(hipMemcpy2DAsync(A, lda * sizeof(double), s->B.A, s->B.ld * sizeof(double), (size_t)s->n * sizeof(double),
+                             (size_t)s->m, hipMemcpyDeviceToHost, s->stream));
+  }
+  if (b && s->m > 0) HIP_TRY(hipMemcpyAsync(b, s->B.b, (size_t)s->m * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (c && s->n > 0) HIP_TRY(hipMemcpyAsync(c, s->B.c, (size_t)s->n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (perm)
+    HIP_TRY(hipMemcpyAsync(perm, s->B.perm, ((size_t)s->n + s->m_global) * sizeof(int32_t), hipMemcpyDeviceToHost,
+                           s->stream));
+  if (int rc = sync_ctl_to_host(s)) return rc;
+  if (v) *v = s->h_ctl->v;
+  return 0;
+}
+
+extern "C" int lpx_state_checksum(lpx_state* s, uint64_t out[3]) {
+  if (!s || !out) return fail(LPX_BAD_ARGUMENT, "NULL argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipMemsetAsync(s->d_sum, 0, 4 * sizeof(unsigned long long), s->stream));
+  lpxk::launch_checksum(s->B, s->m, s->n, s->row0, s->d_sum, s->stream);
+  HIP_TRY(hipGetLastError());
+  unsigned long long h[4];
+  HIP_TRY(hipMemcpyAsync(h, s->d_sum, sizeof h, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+  return 0;
+}
+
+extern "C" int lpx_transpose(int32_t m, int32_t n, const double* A, int64_t lda, double* At, int64_t ldat, int device) {
+  if (m < 0 || n < 0 || (m > 0 && n > 0 && (!A || !At)) || lda < n || ldat < m)
+    return fail(LPX_BAD_ARGUMENT, "lpx_transpose: bad argument");
+  if (m == 0 || n == 0) return 0;
+  HIP_TRY(hipSetDevice(device));
+  double *dA = nullptr, *dAt = nullptr;
+  HIP_TRY(hipMalloc((void**)&dA, (size_t)m * n * sizeof(double)));
+  hipError_t e = hipMalloc((void**)&dAt, (size_t)m * n * sizeof(double));
+  if (e != hipSuccess) { (void)hipFree(dA); return fail(LPX_DEVICE_ERROR, "hipMalloc failed"); }
+  int rc = 0;
+  do {
+    if (hipMemcpy2D(dA, (size_t)n * 8, A, (size_t)lda * 8, (size_t)n * 8, m, hipMemcpyHostToDevice) != hipSuccess) { rc = 1; break; }
+    lpxk::launch_transpose(dA, n, dAt, m, m, n, nullptr);
+    if (hipGetLastError() != hipSuccess) { rc = 1; break; }
+    if (hipMemcpy2D(At, (size_t)ldat * 8, dAt, (size_t)m * 8, (size_t)m * 8, n, hipMemcpyDeviceToHost) != hipSuccess) { rc = 1; break; }
+  } while (0);
+  (void)hipFree(dA);
+  (void)hipFree(dAt);
+  return rc ? fail(LPX_DEVICE_ERROR, "lpx_transpose: HIP error") : 0;
+}
+
+// ------------------------------------------------------------------------------------------------ internals
+// used by lpx_solver.cpp (same shared object, not exported through lpx.h)
+namespace lpx_internal {
+
+int alloc(int32_t m, int32_t n, int32_t n_cap, int device, lpx_state** out) { return alloc_state(m, n, n_cap, 0, m, device, out); }
+void destroy(lpx_state* s) { free_state(s); }
+lpxk::Buffers& buffers(lpx_state* s) { return s->B; }
+hipStream_t stream(lpx_state* s) { return s->stream; }
+LpxCtl* host_ctl(lpx_state* s) { return s->h_ctl; }
+int pull_ctl(lpx_state* s) { return sync_ctl_to_host(s); }
+int push(lpx_state* s) { return push_ctl(s); }
+void reset_ctl(lpx_state* s, double v) { init_ctl(s, v); }
+void set_n(lpx_state* s, int32_t n) { s->n = n; }
+int32_t get_n(lpx_state* s) { return s->n; }
+int32_t get_m(lpx_state* s) { return s->m; }
+int set_error(int status, const char* msg) { return fail(status, msg); }
+
+}  // namespace lpx_internal

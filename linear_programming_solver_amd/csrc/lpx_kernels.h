@@ -1,0 +1,79 @@
+// Internal interface between the HIP kernels (lpx_kernels.hip) and the host engine (lpx_engine.cpp).
+// Not part of the public ABI (that is include/lpx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lpxk {
+
+constexpr int kRunning = -1;     // LpxCtl::status while the loop is live; otherwise an lpx_status value
+constexpr double kEps = 1e-9;    // DEF_EPSILON  reference LPState.java:20
+constexpr double kInf = 1e50;    // DEF_INF      reference LPState.java:21
+
+// (ratio, row) candidate of the minimum-ratio test; "none" is {kInf, INT32_MAX}.
+struct RatioRow {
+  double ratio;
+  int32_t row;   // GLOBAL row index
+  int32_t pad;
+};
+
+// Device-resident loop control: the host never decides anything per pivot, it only polls `status`.
+struct LpxCtl {
+  double v;            // objective constant (LPState.v)
+  double p;            // pivot element A[l][e] of the pivot being applied
+  double bl;           // b[l] / p
+  double pc;           // c[e] before the pivot
+  double ratio;        // winning ratio of the last ratio test
+  int32_t e_next;      // entering slot chosen for the NEXT pivot (-1: none)
+  int32_t e_cur;       // entering slot of the pivot being applied by k_update
+  int32_t l;           // leaving row (GLOBAL index) of the pivot being applied / last ratio test winner
+  int32_t status;      // kRunning or lpx_status
+  int32_t do_update;   // 1 iff k_select_pivot performed a pivot that k_update must apply
+  int32_t track;       // slot of the tracked variable (x0 in phase 1), -1 = none  (LPSolver.java:151-155)
+  int32_t parity;      // col[parity] receives / holds column e_next
+  int32_t reserved;
+  int64_t pivots;      // pivots performed since lpx_simplex_loop started
+  int64_t max_pivots;  // budget for `pivots` (<0: unlimited)
+};
+
+struct Geometry {
+  int U;              // double2 per thread per row in k_update (strip width = 512*U columns)
+  int rows_per_tile;  // rows handled by one k_update block
+  int nstrips, ntiles;
+};
+
+struct Buffers {
+  double* A;          // m_local x ld, row-major, columns [n, ld) are zero
+  int64_t ld;
+  double* b;          // m_local
+  double* c;          // ld (padding zero)
+  double* prow;       // ld: normalised pivot row of the pivot being applied
+  double* col[2];     // m_local each: column e of the tableau (ping-pong, see LpxCtl::parity)
+  RatioRow* partial;  // ntiles
+  int32_t* perm;      // n + m_global
+  LpxCtl* ctl;
+};
+
+// ---- launch wrappers (all asynchronous on `s`) -------------------------------------------------------------
+void launch_entering(const Buffers& B, int n, hipStream_t s);
+// forced_e >= 0: use it as e_next instead of ctl->e_next (step API)
+void launch_ratio_gather(const Buffers& B, int m_local, int row0, const Geometry& g, int forced_e, hipStream_t s);
+void launch_reduce_partials(const Buffers& B, const Geometry& g, hipStream_t s);
+// forced_l >= 0 (global row): pivot(forced_e, forced_l) of the step API, no ratio test
+void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& g, int forced_e, int forced_l,
+                         hipStream_t s);
+void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometry& g, bool nontemporal,
+                   hipStream_t s);
+// shards
+void launch_propose(const Buffers& B, int n, int row0, int m_local, const Geometry& g, double* d_candidate,
+                    hipStream_t s);
+void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, hipStream_t s);
+// phase 1 / restore helpers
+void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
+void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);
+struct RestoreEntry { int32_t is_basic; int32_t index; double k; };  // index = row r (basic) or post-drop slot
+void launch_restore_objective(const Buffers& B, int n, const RestoreEntry* d_entries, int n_entries, hipStream_t s);
+void launch_checksum(const Buffers& B, int m_local, int n, int row0, unsigned long long* d_out3, hipStream_t s);
+void launch_transpose(const double* dA, int64_t lda, double* dAt, int64_t ldat, int m, int n, hipStream_t s);
+
+}  // namespace lpxk

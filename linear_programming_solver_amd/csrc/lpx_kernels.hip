@@ -1,0 +1,623 @@
+// HIP kernels of the dense simplex pivot loop for gfx950 (MI355X / CDNA4).
+//
+// One pivot of the reference (LPState.java:114-181, :274-305, :311-320) is two launches:
+//
+//   k_select_pivot (1 workgroup)  finishes the minimum-ratio test from per-tile partials -> leaving row l,
+//                                 normalises the pivot row (:139-146), updates the objective row, v and the
+//                                 slot permutation (:170-180, :311-320) and picks the NEXT entering slot
+//                                 (first c[j] > 1e-9, :274-285);
+//   k_update      (whole chip)    the rank-1 update of every other row and of b (:151-166): each fp64
+//                                 tableau entry is read once and written once (16 B/entry, HBM-bound,
+//                                 0.125 flop/B -> no MFMA), and — because the next entering slot is already
+//                                 known — the thread that owns that column also emits the next pivot column
+//                                 and the per-tile partial of the next ratio test (:287-305) in the same pass.
+//
+// Arithmetic is IEEE fp64 with exactly one rounding per reference operation (the reference rounds the
+// product and the difference of :162 separately): this file is compiled with -ffp-contract=off and the
+// hot expressions use __dmul_rn/__dsub_rn/__dadd_rn/__ddiv_rn so that no FMA can be formed.
+#include "lpx_kernels.h"
+
+#include <limits.h>
+
+namespace lpxk {
+
+typedef double d2 __attribute__((ext_vector_type(2)));  // one 16-byte global access per lane
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ RatioRow rr_none() { return RatioRow{kInf, INT_MAX, 0}; }
+
+// Lexicographic min on (ratio, row): the sequential scan of LPState.java:292-303 keeps the first row that
+// is STRICTLY smaller than everything before it, i.e. the lowest row among equal minimal ratios.
+__device__ __forceinline__ RatioRow rr_min(RatioRow a, RatioRow b) {
+  const bool take_b = (b.ratio < a.ratio) || (b.ratio == a.ratio && b.row < a.row);
+  return take_b ? b : a;
+}
+
+__device__ __forceinline__ RatioRow rr_wave_min(RatioRow x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    RatioRow y;
+    y.ratio = __shfl_down(x.ratio, off, 64);
+    y.row = __shfl_down(x.row, off, 64);
+    y.pad = 0;
+    x = rr_min(x, y);
+  }
+  return x;
+}
+
+// Block-wide lexmin; result valid in every thread.  `sh` needs blockDim.x/64 entries.
+__device__ __forceinline__ RatioRow rr_block_min(RatioRow x, RatioRow* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  x = rr_wave_min(x);
+  __syncthreads();
+  if (lane == 0) sh[wave] = x;
+  __syncthreads();
+  RatioRow r = sh[0];
+  for (int w = 1; w < nw; ++w) r = rr_min(r, sh[w]);
+  return r;
+}
+
+__device__ __forceinline__ int block_min_int(int x, int* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x = min(x, __shfl_down(x, off, 64));
+  __syncthreads();
+  if (lane == 0) sh[wave] = x;
+  __syncthreads();
+  int r = sh[0];
+  for (int w = 1; w < nw; ++w) r = min(r, sh[w]);
+  return r;
+}
+
+// ratio of one row: LPState.java:293-298
+__device__ __forceinline__ double ratio_of(double a, double bi) {
+  return (a < kEps) ? kInf : __ddiv_rn(bi, a);
+}
+
+// ------------------------------------------------------------------------------------------------ k_entering
+// getEntering(): first slot with c[j] > 1e-9 (LPState.java:274-285).  One workgroup.
+__global__ __launch_bounds__(1024) void k_entering(const double* __restrict__ c, int n, LpxCtl* ctl) {
+  __shared__ int sh[16];
+  if (ctl->status != kRunning) return;
+  int best = INT_MAX;
+  for (int j = threadIdx.x; j < n; j += blockDim.x)
+    if (c[j] > kEps) { best = j; break; }  // per-thread indices ascend, the first hit is this thread's min
+  best = block_min_int(best, sh);
+  if (threadIdx.x == 0) {
+    ctl->e_next = (best == INT_MAX) ? -1 : best;
+    if (best == INT_MAX) ctl->status = 0 /* LPX_OPTIMAL */;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_ratio_gather
+// Seeds the pipeline: strided gather of column e_next into col[parity] plus the per-tile partials of
+// getLeaving (LPState.java:287-305).  Only used for the first pivot of a loop and by the step API; inside
+// the loop k_update produces both as a by-product.
+__global__ __launch_bounds__(256) void k_ratio_gather(const double* __restrict__ A, int64_t ld,
+                                                      const double* __restrict__ b, int m_local, int row0,
+                                                      double* col0, double* col1, RatioRow* partial,
+                                                      const LpxCtl* __restrict__ ctl, int rows_per_tile,
+                                                      int forced_e) {
+  __shared__ RatioRow sh[4];
+  if (ctl->status != kRunning) return;
+  const int e = forced_e >= 0 ? forced_e : ctl->e_next;
+  if (e < 0) return;
+  double* col = ctl->parity ? col1 : col0;
+  const int r0 = blockIdx.x * rows_per_tile;
+  const int r1 = min(m_local, r0 + rows_per_tile);
+  RatioRow best = rr_none();
+  for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+    const double a = A[(int64_t)i * ld + e];
+    col[i] = a;
+    const double r = ratio_of(a, b[i]);
+    if (r < best.ratio) best = RatioRow{r, row0 + i, 0};  // rows ascend per thread: strict < keeps the lowest
+  }
+  best = rr_block_min(best, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = best;
+}
+
+// getLeaving() of the step API: fold the partials into ctl->l / ctl->ratio, no pivot.
+__global__ __launch_bounds__(256) void k_reduce_partials(const RatioRow* __restrict__ partial, int nparts,
+                                                         LpxCtl* ctl) {
+  __shared__ RatioRow sh[4];
+  RatioRow best = rr_none();
+  for (int k = threadIdx.x; k < nparts; k += blockDim.x) best = rr_min(best, partial[k]);
+  best = rr_block_min(best, sh);
+  if (threadIdx.x == 0) {
+    ctl->l = (best.ratio < kInf) ? best.row : -1;
+    ctl->ratio = best.ratio;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pivot finish
+// Shared tail of k_select_pivot (one GPU) and k_commit (shards): given the winning row (raw, un-normalised)
+// normalise it into prow (LPState.java:139-146), update c, v, perm (:170-180, :311-320), follow the tracked
+// slot (LPSolver.java:151-155) and choose the next entering slot (:274-285).  One workgroup of 1024.
+__device__ __forceinline__ void finish_pivot(const double* raw_row, double raw_b, int e, int l_global,
+                                             double* __restrict__ prow, double* __restrict__ c, int n,
+                                             int64_t ld, int32_t* perm, LpxCtl* ctl, int* sh_int) {
+  const double p = raw_row[e];
+  if (p == 0.0) {  // ArithmeticException in the reference (BigDecimal.divide by zero), :139
+    if (threadIdx.x == 0) { ctl->status = 8 /* LPX_DIVIDE_BY_ZERO */; ctl->do_update = 0; }
+    return;
+  }
+  const double pc = c[e];
+  const double bl = __ddiv_rn(raw_b, p);                                           // :146
+  const double inv_p = __ddiv_rn(1.0, p);                                          // :139
+  int first_pos = INT_MAX;
+  __syncthreads();  // every thread has read c[e] before anyone overwrites it
+  for (int j = threadIdx.x; j < (int)ld; j += blockDim.x) {
+    double pr, cn;
+    if (j == e) {
+      pr = inv_p;
+      cn = -__ddiv_rn(pc, p);                                                      // :172
+    } else {
+      const double x = (j < n) ? raw_row[j] : 0.0;
+      pr = __ddiv_rn(x, p);                                                        // :144
+      cn = __dsub_rn(c[j], __dmul_rn(pc, pr));                                     // :177
+    }
+    prow[j] = pr;
+    c[j] = cn;
+    if (j < n && cn > kEps && first_pos == INT_MAX) first_pos = j;
+  }
+  first_pos = block_min_int(first_pos, sh_int);
+  if (threadIdx.x == 0) {
+    ctl->v = __dadd_rn(ctl->v, __dmul_rn(bl, pc));                                 // :171
+    const int32_t t = perm[e];                                                     // exchangeIndexes :311-320
+    perm[e] = perm[n + l_global];
+    perm[n + l_global] = t;
+    if (ctl->track >= 0) {                                                         // LPSolver.java:151-155
+      if (e == ctl->track) ctl->track = l_global + n;
+      else if (l_global + n == ctl->track) ctl->track = e;
+    }
+    ctl->p = p;
+    ctl->bl = bl;
+    ctl->pc = pc;
+    ctl->e_cur = e;
+    ctl->l = l_global;
+    ctl->e_next = (first_pos == INT_MAX) ? -1 : first_pos;
+    if (first_pos == INT_MAX) ctl->status = 0 /* LPX_OPTIMAL: reached after k_update applies this pivot */;
+    ctl->parity ^= 1;  // k_update reads col[parity^1] (column e_cur) and fills col[parity] (column e_next)
+    ctl->pivots += 1;
+    ctl->do_update = 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ k_select_pivot
+__global__ __launch_bounds__(1024) void k_select_pivot(const double* A, int64_t ld, int n, int m_global,
+                                                       const double* b, double* c, double* prow,
+                                                       const RatioRow* partial, int nparts, int32_t* perm,
+                                                       LpxCtl* ctl, int forced_e, int forced_l) {
+  __shared__ RatioRow sh_rr[16];
+  __shared__ int sh_int[16];
+  if (ctl->status != kRunning) {
+    if (threadIdx.x == 0) ctl->do_update = 0;
+    return;
+  }
+  int e, l;
+  if (forced_l >= 0) {  // pivot(entering, leaving) of the step API
+    e = forced_e;
+    l = forced_l;
+  } else {
+    e = ctl->e_next;
+    RatioRow best = rr_none();
+    for (int k = threadIdx.x; k < nparts; k += blockDim.x) best = rr_min(best, partial[k]);
+    best = rr_block_min(best, sh_rr);
+    l = (best.ratio < kInf) ? best.row : -1;
+    if (l < 0) {  // getLeaving() == -1: unbounded (LPSolver.java:103-106 / :147-150)
+      if (threadIdx.x == 0) { ctl->status = 1 /* LPX_UNBOUNDED */; ctl->do_update = 0; ctl->l = -1; ctl->ratio = best.ratio; }
+      return;
+    }
+    if (ctl->max_pivots >= 0 && ctl->pivots >= ctl->max_pivots) {
+      if (threadIdx.x == 0) { ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; }
+      return;
+    }
+    if (threadIdx.x == 0) ctl->ratio = best.ratio;
+  }
+  (void)m_global;
+  finish_pivot(A + (int64_t)l * ld, b[l], e, l, prow, c, n, ld, perm, ctl, sh_int);
+}
+
+// ------------------------------------------------------------------------------------------------ k_update
+// The row update (LPState.java:151-166), the kernel the HBM roofline is quoted on.
+//
+// Work split: workgroup = (tile of rows_per_tile rows) x (strip of 512*U columns); thread t owns the U
+// double2 columns  strip*512*U + k*512 + 2t  (k = 0..U-1), so every wave-level access is 64 x 16 B = 1 KiB
+// contiguous and the thread's slice of the pivot row stays in registers for the whole tile: the pivot row
+// is read once per tile from L2, the multiplier col[i] is one scalar load per row, and every tableau entry
+// moves HBM -> register -> HBM exactly once.  Columns [n, ld) are zero padding that the update maps to zero.
+//
+// The thread that owns column e_next (or column 0 when the pivot being applied ends the loop) also owns
+// the b update, writes the next pivot column into col[parity] and reduces its rows' ratios into
+// partial[tile] — the next getLeaving() costs no extra pass over the tableau.
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_update(double* __restrict__ A, int64_t ld, int m_local, int row0,
+                                                double* __restrict__ b, const double* __restrict__ prow,
+                                                double* col0, double* col1, RatioRow* __restrict__ partial,
+                                                const LpxCtl* __restrict__ ctl, int rows_per_tile,
+                                                int nstrips) {
+  if (ctl->do_update == 0) return;
+  const int strip = blockIdx.x % nstrips;
+  const int tile = blockIdx.x / nstrips;
+  const int e = ctl->e_cur;
+  const int en = ctl->e_next;
+  const int l = ctl->l - row0;  // local index of the pivot row; outside [0, m_local) on other shards
+  const double p = ctl->p;
+  const double bl = ctl->bl;
+  const double* __restrict__ colcur = ctl->parity ? col0 : col1;  // column e_cur (old values)
+  double* __restrict__ colnxt = ctl->parity ? col1 : col0;        // receives column e_next (new values)
+
+  const int cbase = strip * (512 * U) + 2 * threadIdx.x;
+  d2 pr[U];
+  bool act[U];
+  int eslot = -1, oslot = -1;
+  const int oc = en >= 0 ? en : 0;  // owner column of the b update / next-column emission
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int cj = cbase + k * 512;
+    act[k] = cj < (int)ld;
+    pr[k] = act[k] ? *reinterpret_cast<const d2*>(prow + cj) : d2{0.0, 0.0};
+    if (cj == e) eslot = 2 * k;
+    if (cj + 1 == e) eslot = 2 * k + 1;
+    if (cj == oc) oslot = 2 * k;
+    if (cj + 1 == oc) oslot = 2 * k + 1;
+  }
+
+  const int r_begin = tile * rows_per_tile;
+  const int r_end = min(m_local, r_begin + rows_per_tile);
+  RatioRow best = rr_none();
+
+  // two rows per iteration: 2U independent 16-byte loads in flight per thread before the first store
+  for (int i0 = r_begin; i0 < r_end; i0 += 2) {
+    const int i1 = i0 + 1;
+    const bool has1 = i1 < r_end;
+    double* row0p = A + (int64_t)i0 * ld;
+    double* row1p = A + (int64_t)i1 * ld;
+    const double ce0 = colcur[i0];
+    const double ce1 = has1 ? colcur[i1] : 0.0;
+    d2 x0[U], x1[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (act[k]) {
+        const d2* q0 = reinterpret_cast<const d2*>(row0p + cbase + k * 512);
+        x0[k] = NT ? __builtin_nontemporal_load(q0) : *q0;
+      }
+    }
+    if (has1) {
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        if (act[k]) {
+          const d2* q1 = reinterpret_cast<const d2*>(row1p + cbase + k * 512);
+          x1[k] = NT ? __builtin_nontemporal_load(q1) : *q1;
+        }
+      }
+    }
+    // ---- row i0
+    if (i0 == l) {
+#pragma unroll
+      for (int k = 0; k < U; ++k) x0[k] = pr[k];                                  // pivot row := normalised row
+    } else {
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        x0[k].x = __dsub_rn(x0[k].x, __dmul_rn(ce0, pr[k].x));                     // :162
+        x0[k].y = __dsub_rn(x0[k].y, __dmul_rn(ce0, pr[k].y));
+      }
+      if (eslot >= 0) {                                                            // :157
+        const double ne = -__ddiv_rn(ce0, p);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          if (eslot == 2 * k) x0[k].x = ne;
+          if (eslot == 2 * k + 1) x0[k].y = ne;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (act[k]) {
+        d2* q0 = reinterpret_cast<d2*>(row0p + cbase + k * 512);
+        if (NT) __builtin_nontemporal_store(x0[k], q0); else *q0 = x0[k];
+      }
+    }
+    // ---- row i1
+    if (has1) {
+      if (i1 == l) {
+#pragma unroll
+        for (int k = 0; k < U; ++k) x1[k] = pr[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+          x1[k].x = __dsub_rn(x1[k].x, __dmul_rn(ce1, pr[k].x));
+          x1[k].y = __dsub_rn(x1[k].y, __dmul_rn(ce1, pr[k].y));
+        }
+        if (eslot >= 0) {
+          const double ne = -__ddiv_rn(ce1, p);
+#pragma unroll
+          for (int k = 0; k < U; ++k) {
+            if (eslot == 2 * k) x1[k].x = ne;
+            if (eslot == 2 * k + 1) x1[k].y = ne;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        if (act[k]) {
+          d2* q1 = reinterpret_cast<d2*>(row1p + cbase + k * 512);
+          if (NT) __builtin_nontemporal_store(x1[k], q1); else *q1 = x1[k];
+        }
+      }
+    }
+    // ---- owner thread: b update (:164 / :146), next pivot column, next ratio partial (:293-302)
+    if (oslot >= 0) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int i = r ? i1 : i0;
+        if (r && !has1) break;
+        const double ce = r ? ce1 : ce0;
+        const double bn = (i == l) ? bl : __dsub_rn(b[i], __dmul_rn(ce, bl));
+        b[i] = bn;
+        if (en >= 0) {
+          double a = 0.0;
+#pragma unroll
+          for (int k = 0; k < U; ++k) {
+            const d2 xv = r ? x1[k] : x0[k];
+            if (oslot == 2 * k) a = xv.x;
+            if (oslot == 2 * k + 1) a = xv.y;
+          }
+          colnxt[i] = a;
+          const double ratio = ratio_of(a, bn);
+          if (ratio < best.ratio) best = RatioRow{ratio, row0 + i, 0};  // rows ascend: lowest row wins ties
+        }
+      }
+    }
+  }
+  if (oslot >= 0 && en >= 0) partial[tile] = best;
+}
+
+// ------------------------------------------------------------------------------------------------ shards
+// k_propose: fold this shard's partials into its candidate and pack {header, raw row} for the all-gather.
+__global__ __launch_bounds__(1024) void k_propose(const double* __restrict__ A, int64_t ld, int n, int row0,
+                                                  int m_local, const double* __restrict__ b,
+                                                  const RatioRow* __restrict__ partial, int nparts,
+                                                  const LpxCtl* __restrict__ ctl, double* __restrict__ cand) {
+  __shared__ RatioRow sh_rr[16];
+  const int st = ctl->status;
+  RatioRow best = rr_none();
+  if (st == kRunning) {
+    for (int k = threadIdx.x; k < nparts; k += blockDim.x) best = rr_min(best, partial[k]);
+    best = rr_block_min(best, sh_rr);
+  }
+  const bool have = best.ratio < kInf;
+  const int lr = have ? best.row - row0 : -1;
+  if (threadIdx.x == 0) {
+    cand[0] = (st == kRunning) ? 0.0 : (double)(st + 1);
+    cand[1] = (double)ctl->e_next;
+    cand[2] = best.ratio;
+    cand[3] = have ? (double)best.row : -1.0;
+    cand[4] = have ? b[lr] : 0.0;
+    cand[5] = cand[6] = cand[7] = 0.0;
+  }
+  if (have) {
+    const double* row = A + (int64_t)lr * ld;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) cand[8 + j] = row[j];
+  }
+  (void)m_local;
+}
+
+// k_commit: identical on every rank — pick the winner (min ratio, lowest global row) and finish the pivot.
+__global__ __launch_bounds__(1024) void k_commit(const double* __restrict__ gathered, int nranks, int n,
+                                                 int64_t ld, int m_global, double* c, double* prow,
+                                                 int32_t* perm, LpxCtl* ctl) {
+  __shared__ int sh_int[16];
+  if (ctl->status != kRunning) {
+    if (threadIdx.x == 0) ctl->do_update = 0;
+    return;
+  }
+  const int64_t rec = 8 + (int64_t)n;
+  RatioRow best = rr_none();
+  int win = -1;
+  for (int r = 0; r < nranks; ++r) {  // nranks <= 8: every thread scans the headers
+    const double* h = gathered + r * rec;
+    if (h[3] >= 0.0) {
+      const RatioRow cr{h[2], (int32_t)h[3], 0};
+      const bool take = (cr.ratio < best.ratio) || (cr.ratio == best.ratio && cr.row < best.row);
+      if (take) { best = cr; win = r; }
+    }
+  }
+  if (win < 0 || !(best.ratio < kInf)) {
+    if (threadIdx.x == 0) { ctl->status = 1 /* LPX_UNBOUNDED */; ctl->do_update = 0; ctl->l = -1; ctl->ratio = best.ratio; }
+    return;
+  }
+  if (ctl->max_pivots >= 0 && ctl->pivots >= ctl->max_pivots) {
+    if (threadIdx.x == 0) { ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; }
+    return;
+  }
+  const int e = ctl->e_next;
+  if (threadIdx.x == 0) ctl->ratio = best.ratio;
+  const double* h = gathered + win * rec;
+  (void)m_global;
+  finish_pivot(h + 8, h[4], e, best.row, prow, c, n, ld, perm, ctl, sh_int);
+}
+
+// ------------------------------------------------------------------------------------------------ phase 1 helpers
+// convertIntoAuxLP: auxA[i][n] = -1 (LPSolver.java:293)
+__global__ void k_fill_column(double* A, int64_t ld, int m, int col, double value) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) A[(int64_t)i * ld + col] = value;
+}
+
+// restoreInitialLP: drop x0's column in place (LPSolver.java:208-211).  One workgroup per row; chunks are
+// shifted left by one in increasing order, with a barrier between the chunk's reads and its writes.
+__global__ __launch_bounds__(256) void k_drop_column(double* A, int64_t ld, int m, int n_old, int col) {
+  const int i = blockIdx.x;
+  if (i >= m) return;
+  double* row = A + (int64_t)i * ld;
+  for (int base = col; base < n_old; base += blockDim.x) {
+    const int j = base + threadIdx.x;
+    double x = 0.0;
+    if (j + 1 < n_old) x = row[j + 1];  // the vacated last column becomes zero padding again
+    __syncthreads();
+    if (j < n_old) row[j] = x;
+    __syncthreads();
+  }
+}
+
+// restoreInitialLP: rebuild c and v by substitution (LPSolver.java:213-233), entries in keySet() order.
+// Thread j accumulates c[j] over the entries in order — the same sequence of rounded additions per element
+// as the reference; thread 0 of block 0 accumulates v.
+__global__ __launch_bounds__(256) void k_restore_objective(const double* __restrict__ A, int64_t ld,
+                                                           const double* __restrict__ b, double* c, int n,
+                                                           const RestoreEntry* __restrict__ ent, int n_ent,
+                                                           LpxCtl* ctl) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) {
+    double acc = 0.0;
+    for (int t = 0; t < n_ent; ++t) {
+      const RestoreEntry en = ent[t];
+      if (en.is_basic) {
+        const double coef = -A[(int64_t)en.index * ld + j];                        // :226
+        acc = __dadd_rn(acc, __dmul_rn(coef, en.k));                               // :227
+      } else if (en.index == j) {
+        acc = __dadd_rn(acc, en.k);                                                // :231
+      }
+    }
+    c[j] = acc;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double v = 0.0;
+    for (int t = 0; t < n_ent; ++t)
+      if (ent[t].is_basic) v = __dadd_rn(v, __dmul_rn(b[ent[t].index], ent[t].k)); // :223
+    ctl->v = v;
+  }
+}
+
+// Position-keyed, order-independent checksum of bit patterns (parity of full-size tableaux without a
+// read-back): sum over elements of mix(bits + (pos+1)*K1) mod 2^64.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long bits, unsigned long long pos) {
+  unsigned long long h = bits + (pos + 1ull) * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 27; h *= 0x94D049BB133111EBull;
+  h ^= h >> 31;
+  return h;
+}
+
+__global__ __launch_bounds__(256) void k_checksum(const double* __restrict__ A, int64_t ld, int m_local, int n,
+                                                  int row0, const double* __restrict__ b,
+                                                  const double* __restrict__ c, unsigned long long* out) {
+  unsigned long long sa = 0, sb = 0, sc = 0;
+  const int64_t total = (int64_t)m_local * n;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = idx / n, j = idx - i * n;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(A[i * ld + j]);
+    sa += mix64(bits, (unsigned long long)((row0 + i) * (int64_t)n + j));
+  }
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < m_local; i += blockDim.x)
+      sb += mix64((unsigned long long)__double_as_longlong(b[i]), (unsigned long long)(row0 + i));
+    for (int j = threadIdx.x; j < n; j += blockDim.x)
+      sc += mix64((unsigned long long)__double_as_longlong(c[j]), (unsigned long long)j);
+  }
+  // wave reduce then one atomic per wave
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sa += __shfl_down(sa, off, 64);
+    sb += __shfl_down(sb, off, 64);
+    sc += __shfl_down(sc, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], sa);
+    if (blockIdx.x == 0) { atomicAdd(&out[1], sb); atomicAdd(&out[2], sc); }
+  }
+}
+
+// LPStandardForm.getDual(): tiled transpose through LDS (64x64 tile, +1 padding against bank conflicts).
+__global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ A, int64_t lda,
+                                                   double* __restrict__ At, int64_t ldat, int m, int n) {
+  __shared__ double tile[64][65];
+  const int bx = blockIdx.x * 64, by = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  for (int r = ty; r < 64; r += 4) {
+    const int i = by + r, j = bx + tx;
+    if (i < m && j < n) tile[r][tx] = A[(int64_t)i * lda + j];
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int j = bx + r, i = by + tx;
+    if (j < n && i < m) At[(int64_t)j * ldat + i] = tile[tx][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+void launch_entering(const Buffers& B, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_entering, dim3(1), dim3(1024), 0, s, B.c, n, B.ctl);
+}
+
+void launch_ratio_gather(const Buffers& B, int m_local, int row0, const Geometry& g, int forced_e, hipStream_t s) {
+  if (g.ntiles <= 0) return;
+  hipLaunchKernelGGL(k_ratio_gather, dim3(g.ntiles), dim3(256), 0, s, B.A, B.ld, B.b, m_local, row0, B.col[0],
+                     B.col[1], B.partial, B.ctl, g.rows_per_tile, forced_e);
+}
+
+void launch_reduce_partials(const Buffers& B, const Geometry& g, hipStream_t s) {
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, B.partial, g.ntiles, B.ctl);
+}
+
+void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& g, int forced_e, int forced_l,
+                         hipStream_t s) {
+  hipLaunchKernelGGL(k_select_pivot, dim3(1), dim3(1024), 0, s, B.A, B.ld, n, m_global, B.b, B.c, B.prow,
+                     B.partial, g.ntiles, B.perm, B.ctl, forced_e, forced_l);
+}
+
+template <int U, bool NT>
+static void launch_update_t(const Buffers& B, int m_local, int row0, const Geometry& g, hipStream_t s) {
+  hipLaunchKernelGGL((k_update<U, NT>), dim3(g.nstrips * g.ntiles), dim3(256), 0, s, B.A, B.ld, m_local, row0,
+                     B.b, B.prow, B.col[0], B.col[1], B.partial, B.ctl, g.rows_per_tile, g.nstrips);
+}
+
+void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometry& g, bool nt, hipStream_t s) {
+  (void)n;
+  if (g.ntiles <= 0 || g.nstrips <= 0) return;
+  switch (g.U) {
+    case 1: nt ? launch_update_t<1, true>(B, m_local, row0, g, s) : launch_update_t<1, false>(B, m_local, row0, g, s); break;
+    case 2: nt ? launch_update_t<2, true>(B, m_local, row0, g, s) : launch_update_t<2, false>(B, m_local, row0, g, s); break;
+    default: nt ? launch_update_t<4, true>(B, m_local, row0, g, s) : launch_update_t<4, false>(B, m_local, row0, g, s); break;
+  }
+}
+
+void launch_propose(const Buffers& B, int n, int row0, int m_local, const Geometry& g, double* d_candidate,
+                    hipStream_t s) {
+  hipLaunchKernelGGL(k_propose, dim3(1), dim3(1024), 0, s, B.A, B.ld, n, row0, m_local, B.b, B.partial,
+                     g.ntiles, B.ctl, d_candidate);
+}
+
+void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, hipStream_t s) {
+  hipLaunchKernelGGL(k_commit, dim3(1), dim3(1024), 0, s, d_gathered, nranks, n, B.ld, m_global, B.c, B.prow,
+                     B.perm, B.ctl);
+}
+
+void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(k_fill_column, dim3((m + 255) / 256), dim3(256), 0, s, A, ld, m, col, value);
+}
+
+void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(k_drop_column, dim3(m), dim3(256), 0, s, A, ld, m, n_old, col);
+}
+
+void launch_restore_objective(const Buffers& B, int n, const RestoreEntry* d_entries, int n_entries, hipStream_t s) {
+  const int blocks = n > 0 ? (n + 255) / 256 : 1;
+  hipLaunchKernelGGL(k_restore_objective, dim3(blocks), dim3(256), 0, s, B.A, B.ld, B.b, B.c, n, d_entries,
+                     n_entries, B.ctl);
+}
+
+void launch_checksum(const Buffers& B, int m_local, int n, int row0, unsigned long long* d_out3, hipStream_t s) {
+  hipLaunchKernelGGL(k_checksum, dim3(1024), dim3(256), 0, s, B.A, B.ld, m_local, n, row0, B.b, B.c, d_out3);
+}
+
+void launch_transpose(const double* dA, int64_t lda, double* dAt, int64_t ldat, int m, int n, hipStream_t s) {
+  if (m <= 0 || n <= 0) return;
+  hipLaunchKernelGGL(k_transpose, dim3((n + 63) / 64, (m + 63) / 64), dim3(256), 0, s, dA, lda, dAt, ldat, m, n);
+}
+
+}  // namespace lpxk

@@ -1,0 +1,317 @@
+// LPSolver.solve behind the C ABI (include/lpx.h): the driver logic of the reference's LPSolver.java —
+// min->max flip (:86-90), initializeSimplex (:116-133), the auxiliary LP of phase 1 (:135-198, :283-321)
+// and restoreInitialLP (:200-246, reproduced bug-for-bug) — around the device-resident pivot loop.  Only
+// O(n + m) scalars ever cross the host/device boundary after the upload: the tableau stays in HBM.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lpx.h"
+#include "lpx_kernels.h"
+
+namespace lpx_internal {
+int alloc(int32_t m, int32_t n, int32_t n_cap, int device, lpx_state** out);
+void destroy(lpx_state* s);
+lpxk::Buffers& buffers(lpx_state* s);
+hipStream_t stream(lpx_state* s);
+lpxk::LpxCtl* host_ctl(lpx_state* s);
+int pull_ctl(lpx_state* s);
+int push(lpx_state* s);
+void reset_ctl(lpx_state* s, double v);
+void set_n(lpx_state* s, int32_t n);
+int32_t get_n(lpx_state* s);
+int32_t get_m(lpx_state* s);
+int set_error(int status, const char* msg);
+}  // namespace lpx_internal
+
+using namespace lpx_internal;
+
+#define HIP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) return set_error(LPX_DEVICE_ERROR, hipGetErrorString(_e));   \
+  } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// java.util.HashMap<String,Integer> iteration order after put("x1") .. put("xn") into `new HashMap<>()`
+// (LPSolver.addDefaultVariables, LPSolver.java:388-400): String.hashCode is s[0]*31^(k-1)+...; HashMap
+// spreads h ^ (h >>> 16), indexes with (cap-1) & hash, doubles the table from 16 whenever size exceeds
+// 0.75*cap (splitting preserves relative order) and iterates buckets in index order, entries of a bucket
+// in insertion order.  A bucket is only treeified at >= 8 entries; "x<k>" keys stay far below that, and if
+// they ever did not the order falls back to insertion order (documented deviation).
+extern "C" int lpx_java_default_name_order(int32_t n, int32_t* order_out) {
+  if (n < 0 || (n > 0 && !order_out)) return set_error(LPX_BAD_ARGUMENT, "lpx_java_default_name_order: bad argument");
+  if (n == 0) return 0;
+  size_t cap = 16;
+  while ((double)n > 0.75 * (double)cap) cap <<= 1;
+  std::vector<int32_t> count(cap, 0), bucket_of(n);
+  for (int k = 1; k <= n; k++) {
+    char name[32];
+    const int len = snprintf(name, sizeof name, "x%d", k);
+    uint32_t h = 0;
+    for (int i = 0; i < len; i++) h = h * 31u + (uint32_t)(unsigned char)name[i];
+    h ^= h >> 16;
+    bucket_of[k - 1] = (int32_t)(h & (cap - 1));
+    count[bucket_of[k - 1]]++;
+  }
+  bool treeified = false;
+  for (size_t i = 0; i < cap; i++) treeified |= count[i] >= 8;
+  if (treeified) {
+    for (int k = 0; k < n; k++) order_out[k] = k;
+    return 0;
+  }
+  std::vector<int32_t> start(cap + 1, 0);
+  for (size_t i = 0; i < cap; i++) start[i + 1] = start[i] + count[i];
+  std::vector<int32_t> fill(start.begin(), start.end() - 1);
+  for (int k = 0; k < n; k++) order_out[fill[bucket_of[k]]++] = k;  // stable: insertion order inside a bucket
+  return 0;
+}
+
+// new BigDecimal(v).setScale(6, RoundingMode.HALF_UP) (LPSolver.java:113) as text: the exact binary value
+// of the double is expanded and the first discarded digit decides.
+static void round6_text(double v, char* out, size_t cap) {
+  static thread_local char buf[1400];
+  if (!std::isfinite(v)) { snprintf(out, cap, "%g", v); return; }
+  snprintf(buf, sizeof buf, "%.1100f", v);
+  std::string s(buf);
+  const bool neg = s[0] == '-';
+  const size_t dot = s.find('.');
+  std::string digits = s.substr(neg ? 1 : 0, dot - (neg ? 1 : 0)) + s.substr(dot + 1, 6);
+  if (s[dot + 7] >= '5') {
+    int i = (int)digits.size() - 1;
+    while (i >= 0) {
+      if (digits[i] == '9') { digits[i] = '0'; i--; }
+      else { digits[i]++; break; }
+    }
+    if (i < 0) digits.insert(digits.begin(), '1');
+  }
+  bool all_zero = true;
+  for (char ch : digits) all_zero &= ch == '0';
+  std::string r = digits.substr(0, digits.size() - 6) + "." + digits.substr(digits.size() - 6);
+  if (neg && !all_zero) r = "-" + r;  // BigDecimal has no negative zero
+  snprintf(out, cap, "%s", r.c_str());
+}
+
+// LPSolver.java:375-386
+static int min_in_b(const double* b, int m) {
+  double mn = 1e50;
+  int idx = -1;
+  for (int i = 0; i < m; i++)
+    if (mn > b[i]) { mn = b[i]; idx = i; }
+  return idx;
+}
+
+namespace {
+struct Cleanup {
+  lpx_state* s = nullptr;
+  lpxk::RestoreEntry* d_ent = nullptr;
+  ~Cleanup() {
+    if (d_ent) (void)hipFree(d_ent);
+    if (s) destroy(s);
+  }
+};
+}  // namespace
+
+extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, const double* b, const double* c,
+                         int32_t maximize, const lpx_solve_options* opts, lpx_solve_result* res) {
+  if (!res) return set_error(LPX_BAD_ARGUMENT, "lpx_solve: result is NULL");
+  memset(res, 0, sizeof *res);
+  res->x0_slot = -1;
+  res->status = LPX_BAD_ARGUMENT;
+  if (m < 0 || n < 0 || (m > 0 && n > 0 && !A) || (m > 0 && !b) || (n > 0 && !c) || (m > 0 && n > 0 && lda < n))
+    return set_error(LPX_BAD_ARGUMENT, "lpx_solve: bad argument");
+  const double t_start = now_s();
+  lpx_solve_options o{};
+  if (opts) o = *opts;
+  const int64_t max_pivots = opts ? o.max_pivots : -1;
+  if (o.keep_state) *o.keep_state = nullptr;
+
+  // :86-89 — the reference negates stForm.c in place for `min`; here on a private copy
+  std::vector<double> c0(c, c + n);
+  if (!maximize)
+    for (auto& x : c0) x = -x;
+
+  const int mib = min_in_b(b, m);                                                   // :118
+  const bool phase1 = !(mib == -1 || b[mib] >= 0.0);                                // :119
+  const int n_cap = phase1 ? n + 1 : n;
+  Cleanup guard;
+  lpx_state* s = nullptr;
+  if (int rc = alloc(m, n_cap, n_cap, o.device, &s)) { res->status = rc; return rc; }
+  guard.s = s;
+  hipStream_t st = stream(s);
+  lpxk::Buffers& B = buffers(s);
+  double t_pivots = 0.0;
+  int status = LPX_OPTIMAL;
+
+  // upload A (m x n) into the m x ld device tableau; b; perm
+  if (m > 0 && n > 0)
+    HIP_TRY(hipMemcpy2DAsync(B.A, B.ld * sizeof(double), A, lda * sizeof(double), (size_t)n * sizeof(double), (size_t)m,
+                             hipMemcpyHostToDevice, st));
+  if (m > 0) HIP_TRY(hipMemcpyAsync(B.b, b, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st));
+
+  std::vector<int32_t> perm;
+  if (!phase1) {
+    // convertIntoSlackForm :248-272 — ids: originals 0..n-1, slacks n..n+m-1
+    if (n > 0) HIP_TRY(hipMemcpyAsync(B.c, c0.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    perm.resize((size_t)n + m);
+    for (size_t i = 0; i < perm.size(); i++) perm[i] = (int32_t)i;
+    if (!perm.empty())
+      HIP_TRY(hipMemcpyAsync(B.perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    reset_ctl(s, 0.0);
+    if (int rc = push(s)) { res->status = rc; return rc; }
+    HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    res->phase1_used = 1;
+    // convertIntoAuxLP :283-321 — extra column of -1, objective -x0; x0 has id n+m and starts in slot n
+    const int na = n + 1;
+    lpxk::launch_fill_column(B.A, B.ld, m, n, -1.0, st);                              // :293
+    std::vector<double> auxc(na, 0.0);
+    auxc[n] = -1.0;                                                                  // :299-301
+    HIP_TRY(hipMemcpyAsync(B.c, auxc.data(), (size_t)na * sizeof(double), hipMemcpyHostToDevice, st));
+    perm.resize((size_t)na + m);
+    for (int j = 0; j < n; j++) perm[j] = j;
+    perm[n] = n + m;
+    for (int i = 0; i < m; i++) perm[na + i] = n + i;
+    HIP_TRY(hipMemcpyAsync(B.perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    reset_ctl(s, 0.0);
+    if (int rc = push(s)) { res->status = rc; return rc; }
+    HIP_TRY(hipStreamSynchronize(st));
+
+    // solveAuxLP :135-164
+    double t0 = now_s();
+    int rc = lpx_pivot(s, na - 1, mib);                                              // :138
+    if (rc) { res->status = rc; return rc; }
+    res->pivots_phase1 = 1;
+    int32_t x0 = mib + na;                                                           // :139
+    int64_t done = 0;
+    int32_t lst = 0;
+    const int64_t lim1 = max_pivots < 0 ? -1 : std::max<int64_t>(0, max_pivots - 1);
+    rc = lpx_simplex_loop(s, lim1, &done, &lst, &x0);
+    t_pivots += now_s() - t0;
+    if (rc) { res->status = rc; return rc; }
+    res->pivots_phase1 += done;
+    res->x0_slot = x0;
+    if (lst == LPX_UNBOUNDED) status = LPX_AUX_UNBOUNDED;                            // :147-150
+    else if (lst == LPX_PIVOT_LIMIT) status = LPX_PIVOT_LIMIT;
+    if (status == LPX_OPTIMAL) {
+      // handleInitialization :166-180
+      double x0_value = 0.0;
+      if (x0 >= na) HIP_TRY(hipMemcpy(&x0_value, B.b + (x0 - na), sizeof(double), hipMemcpyDeviceToHost));
+      if (std::fabs(x0_value) > 1e-9) status = LPX_INFEASIBLE;                       // :171-174
+    }
+    if (status == LPX_OPTIMAL && x0 >= na) {
+      // performDegeneratePivot :182-198 — first slot with |A[row][i]| > eps
+      const int row = x0 - na;
+      std::vector<double> hrow(na);
+      HIP_TRY(hipMemcpy(hrow.data(), B.A + (int64_t)row * B.ld, (size_t)na * sizeof(double), hipMemcpyDeviceToHost));
+      int entering = -1;
+      for (int i = 0; i < na; i++)
+        if (std::fabs(hrow[i]) > 1e-9) { entering = i; break; }
+      if (entering == -1) status = LPX_NO_DEGENERATE_PIVOT;                          // :192-194
+      else {
+        t0 = now_s();
+        rc = lpx_pivot(s, entering, row);                                            // :195
+        t_pivots += now_s() - t0;
+        if (rc) { res->status = rc; return rc; }
+        res->pivots_phase1 += 1;
+        x0 = entering;
+        res->x0_slot = x0;
+      }
+    }
+    if (status == LPX_OPTIMAL) {
+      // restoreInitialLP :200-246
+      HIP_TRY(hipMemcpy(perm.data(), B.perm, perm.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      std::vector<int32_t> slot_of((size_t)n + m + 1, -1);                            // auxLP.coefficients
+      for (int sl = 0; sl < na + m; sl++) slot_of[perm[sl]] = sl;
+      std::vector<int32_t> order(n);
+      if (o.restore_order) order.assign(o.restore_order, o.restore_order + n);
+      else lpx_java_default_name_order(n, order.data());
+      std::vector<lpxk::RestoreEntry> ent;
+      ent.reserve(n);
+      for (int32_t index : order) {                                                  // :217
+        if (index < 0 || index >= n) { status = LPX_BAD_ARGUMENT; break; }
+        const int cur = slot_of[index];                                              // :220
+        lpxk::RestoreEntry e{};
+        e.k = c0[index];                                                             // :219
+        if (cur >= na) { e.is_basic = 1; e.index = cur - na; }                       // :221-228
+        else {
+          if (cur >= n) { status = LPX_RESTORE_INDEX_FAULT; break; }                 // AIOOBE at :231
+          e.is_basic = 0; e.index = cur;  // :231 bug-for-bug: an aux-LP slot used as a post-drop index
+        }
+        ent.push_back(e);
+      }
+      if (status == LPX_OPTIMAL) {
+        lpxk::launch_drop_column(B.A, B.ld, m, na, x0, st);                            // :208-211
+        HIP_TRY(hipMemsetAsync(B.c, 0, (size_t)B.ld * sizeof(double), st));
+        if (!ent.empty()) {
+          HIP_TRY(hipMalloc((void**)&guard.d_ent, ent.size() * sizeof(lpxk::RestoreEntry)));
+          HIP_TRY(hipMemcpyAsync(guard.d_ent, ent.data(), ent.size() * sizeof(lpxk::RestoreEntry), hipMemcpyHostToDevice, st));
+        }
+        reset_ctl(s, 0.0);
+        if (int rc2 = push(s)) { res->status = rc2; return rc2; }
+        lpxk::launch_restore_objective(B, n, guard.d_ent, (int)ent.size(), st);      // :213-233 (sets ctl.v)
+        std::vector<int32_t> np;                                                     // :235-244
+        np.reserve((size_t)n + m);
+        for (int sl = 0; sl < na + m; sl++)
+          if (sl != x0) np.push_back(perm[sl]);
+        perm.swap(np);
+        HIP_TRY(hipMemcpyAsync(B.perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipGetLastError());
+        set_n(s, n);
+      }
+    }
+  }
+
+  if (status == LPX_OPTIMAL) {
+    // LPSolver.simplex :96-114
+    const double t0 = now_s();
+    int64_t done = 0;
+    int32_t lst = 0;
+    int64_t lim2 = max_pivots < 0 ? -1 : std::max<int64_t>(0, max_pivots - res->pivots_phase1);
+    int rc = lpx_simplex_loop(s, lim2, &done, &lst, nullptr);
+    t_pivots += now_s() - t0;
+    if (rc) { res->status = rc; return rc; }
+    res->pivots_phase2 = done;
+    status = lst;
+  }
+
+  // result
+  if (int rc = pull_ctl(s)) { res->status = rc; return rc; }
+  double v = host_ctl(s)->v;
+  if (!maximize) v = -v;                                                             // :90
+  res->objective = v;
+  round6_text(v, res->objective_text, sizeof res->objective_text);                   // :113
+  res->objective_rounded = strtod(res->objective_text, nullptr);
+  res->status = status;
+  const int32_t fn = get_n(s);
+  if (o.perm_out || o.x_out) {
+    std::vector<int32_t> fp((size_t)fn + m);
+    if (!fp.empty()) HIP_TRY(hipMemcpy(fp.data(), B.perm, fp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (o.perm_out) memcpy(o.perm_out, fp.data(), fp.size() * sizeof(int32_t));
+    if (o.x_out && fn == n) {
+      // solution vector (the reference's commented-out printSolution, LPSolver.java:344-374):
+      // a basic original variable takes b[row], every nonbasic one is 0
+      std::vector<double> hb(m);
+      if (m > 0) HIP_TRY(hipMemcpy(hb.data(), B.b, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+      for (int j = 0; j < n; j++) o.x_out[j] = 0.0;
+      for (int i = 0; i < m; i++) {
+        const int32_t id = fp[(size_t)n + i];
+        if (id >= 0 && id < n) o.x_out[id] = hb[i];
+      }
+    }
+  }
+  res->seconds_pivots = t_pivots;
+  res->seconds_total = now_s() - t_start;
+  if (o.keep_state) { *o.keep_state = s; guard.s = nullptr; }
+  if (status != LPX_OPTIMAL) set_error(status, lpx_status_message(status));
+  return status;
+}

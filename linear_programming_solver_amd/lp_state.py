@@ -1,0 +1,177 @@
+"""LPState: the device-resident slack-form tableau and the three simplex primitives of the reference
+(LPState.java:17-320) over the C ABI of liblpx.so.  Same operator names and argument meaning as the
+reference so the parity tests read like LPStateSpec.groovy."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .errors import raise_for_status
+
+
+class LPState:
+    def __init__(self, A, b, c, v=0.0, variables=None, coefficients=None, m=None, n=None, device=0,
+                 perm=None, row0=0, m_global=None):
+        """new LPState(A, b, c, v, variables, coefficients, m, n)  (LPState.java:101-112).
+        `variables`/`coefficients` are the reference's name maps (slot -> name / name -> slot); they are
+        kept on the host and permuted from the device's slot permutation on demand."""
+        L = _lib.lib()
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.float64)).reshape(-1)
+        c = np.ascontiguousarray(np.asarray(c, dtype=np.float64)).reshape(-1)
+        self.m = int(b.size if m is None else m)
+        self.n = int(c.size if n is None else n)
+        A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
+        A = A.reshape(self.m, self.n) if A.size == self.m * self.n else np.zeros((self.m, self.n))
+        self.row0 = int(row0)
+        self.m_global = int(self.m if m_global is None else m_global)
+        self._names0 = None
+        if variables is not None and coefficients is not None:
+            self._names0 = [variables.get(s) for s in range(self.n + self.m_global)]
+        p = None if perm is None else np.ascontiguousarray(np.asarray(perm, dtype=np.int32))
+        h = C.c_void_p()
+        rc = L.lpx_state_create(self.m, self.n, A.ctypes.data_as(_lib.dp), max(self.n, 1), b.ctypes.data_as(_lib.dp),
+                                c.ctypes.data_as(_lib.dp), float(v), None if p is None else p.ctypes.data_as(_lib.ip),
+                                self.row0, self.m_global, int(device), C.byref(h))
+        if rc:
+            raise_for_status(rc)
+        self._h = h
+        self._L = L
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lpx_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- the operator triple
+    def get_entering(self):                                      # LPState.java:274
+        e = C.c_int32()
+        rc = self._L.lpx_get_entering(self._h, C.byref(e))
+        if rc:
+            raise_for_status(rc)
+        return e.value
+
+    def get_leaving(self, entering):                             # LPState.java:287
+        l = C.c_int32()
+        r = C.c_double()
+        rc = self._L.lpx_get_leaving(self._h, int(entering), C.byref(l), C.byref(r))
+        if rc:
+            raise_for_status(rc)                                 # ValueError <-> IllegalArgumentException
+        return l.value
+
+    def pivot(self, entering, leaving):                          # LPState.java:114
+        rc = self._L.lpx_pivot(self._h, int(entering), int(leaving))
+        if rc:
+            raise_for_status(rc)
+
+    getEntering, getLeaving = get_entering, get_leaving
+
+    def simplex_loop(self, max_pivots=-1, track_slot=None):
+        """The loop of LPSolver.simplex (LPSolver.java:101-107), device-resident.
+        Returns (status, pivots_done, tracked_slot)."""
+        piv = C.c_int64()
+        st = C.c_int32()
+        tr = C.c_int32(-1 if track_slot is None else int(track_slot))
+        rc = self._L.lpx_simplex_loop(self._h, int(max_pivots), C.byref(piv), C.byref(st),
+                                      C.byref(tr) if track_slot is not None else None)
+        if rc:
+            raise_for_status(rc)
+        return st.value, piv.value, (tr.value if track_slot is not None else None)
+
+    # -- read-back
+    def read(self, want_A=True):
+        A = np.zeros((self.m, self.n)) if want_A else None
+        b = np.zeros(self.m)
+        c = np.zeros(self.n)
+        v = C.c_double()
+        perm = np.zeros(self.n + self.m_global, dtype=np.int32)
+        rc = self._L.lpx_state_read(self._h, A.ctypes.data_as(_lib.dp) if want_A and A.size else None, max(self.n, 1),
+                                    b.ctypes.data_as(_lib.dp) if self.m else None,
+                                    c.ctypes.data_as(_lib.dp) if self.n else None, C.byref(v),
+                                    perm.ctypes.data_as(_lib.ip))
+        if rc:
+            raise_for_status(rc)
+        return A, b, c, v.value, perm
+
+    @property
+    def A(self):
+        return self.read()[0]
+
+    @property
+    def b(self):
+        return self.read(False)[1]
+
+    @property
+    def c(self):
+        return self.read(False)[2]
+
+    @property
+    def v(self):
+        return self.read(False)[3]
+
+    @property
+    def perm(self):
+        return self.read(False)[4]
+
+    @property
+    def variables(self):
+        """slot -> name, i.e. the reference's `variables` map after exchangeIndexes (LPState.java:311-320)."""
+        if self._names0 is None:
+            return None
+        perm = self.perm
+        return {s: self._names0[int(perm[s])] for s in range(len(perm))}
+
+    @property
+    def coefficients(self):
+        v = self.variables
+        return None if v is None else {name: s for s, name in v.items()}
+
+    def checksum(self):
+        out = (C.c_uint64 * 3)()
+        rc = self._L.lpx_state_checksum(self._h, out)
+        if rc:
+            raise_for_status(rc)
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def profile_enable(self, on=True):
+        rc = self._L.lpx_profile_enable(self._h, 1 if on else 0)
+        if rc:
+            raise_for_status(rc)
+
+    def profile_read(self):
+        n = C.c_int64()
+        ms = C.c_double()
+        rc = self._L.lpx_profile_read(self._h, C.byref(n), C.byref(ms))
+        if rc:
+            raise_for_status(rc)
+        return n.value, ms.value
+
+
+def checksum_host(A, b, c, row0=0):
+    """Host restatement of lpx_state_checksum (position-keyed sum of mixed bit patterns, mod 2^64)."""
+    def mix(bits, pos):
+        with np.errstate(over="ignore"):
+            h = bits + (pos + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+            h ^= h >> np.uint64(30)
+            h *= np.uint64(0xBF58476D1CE4E5B9)
+            h ^= h >> np.uint64(27)
+            h *= np.uint64(0x94D049BB133111EB)
+            h ^= h >> np.uint64(31)
+        return h
+
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    m, n = A.shape
+    with np.errstate(over="ignore"):
+        posA = (np.arange(m, dtype=np.uint64)[:, None] + np.uint64(row0)) * np.uint64(n) + np.arange(n, dtype=np.uint64)[None, :]
+        sa = int(np.sum(mix(A.view(np.uint64), posA), dtype=np.uint64)) if A.size else 0
+        bb = np.ascontiguousarray(b, dtype=np.float64)
+        sb = int(np.sum(mix(bb.view(np.uint64), np.arange(bb.size, dtype=np.uint64) + np.uint64(row0)), dtype=np.uint64)) if bb.size else 0
+        cc = np.ascontiguousarray(c, dtype=np.float64)
+        sc = int(np.sum(mix(cc.view(np.uint64), np.arange(cc.size, dtype=np.uint64)), dtype=np.uint64)) if cc.size else 0
+    return sa, sb, sc

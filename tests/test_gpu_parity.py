@@ -1,0 +1,321 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (liblpx.so via the host mirror classes),
+against the oracle on the same inputs.
+
+Bars: bit-exact against the fp64 instantiation of the oracle (every tableau entry, b, c, v, the slot
+permutation, pivot counts and statuses); against the decimal-15 instantiation (the reference's BigDecimal
+semantics) identical pivot sequence / basis and objective within OBJ_TOL.  The reference's own Spock vectors
+are replayed through the device as well."""
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+OBJ_TOL = 1e-9           # |v_gpu - v_decimal| <= OBJ_TOL * max(1, |v|)   (north_star tolerance)
+STATUS = {"OPTIMAL": 0, "UNBOUNDED": 1, "INFEASIBLE": 2}
+
+
+@pytest.fixture(scope="module")
+def lps():
+    import linear_programming_solver_amd as pkg
+    from linear_programming_solver_amd import _lib
+    _lib.lib()
+    assert _lib.lib().lpx_device_count() >= 1, "no HIP device visible"
+    return pkg
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_state_bits_equal(got, want, what=""):
+    gA, gb, gc, gv, gp = got
+    wA, wb, wc, wv, wp = want
+    assert np.array_equal(bits(gA), bits(wA)), "A differs " + what
+    assert np.array_equal(bits(gb), bits(wb)), "b differs " + what
+    assert np.array_equal(bits(gc), bits(wc)), "c differs " + what
+    assert bits(np.array([gv]))[0] == bits(np.array([wv]))[0], "v differs %s: %r vs %r" % (what, gv, wv)
+    if wp is not None:
+        assert list(gp) == list(wp), "perm differs " + what
+
+
+def dense_lp(m, n, seed):
+    """SURVEY §8(d) synthetic input: A ~ U(0,1), b = (n/4) U(1,2), c ~ U(0,1), maximise."""
+    rng = np.random.default_rng(seed)
+    return rng.random((m, n)), (n / 4.0) * (1.0 + rng.random(m)), rng.random(n)
+
+
+# ------------------------------------------------------------------------------------ reference vectors
+def test_reference_get_entering(lps, reference_vectors):          # LPStateSpec.groovy:12-29
+    for case in reference_vectors["get_entering"]["cases"]:
+        c = case["c"]
+        st = lps.LPState(np.zeros((0, len(c))), [], c)
+        assert st.get_entering() == case["entering"], case
+        st.close()
+
+
+def test_reference_get_leaving(lps, reference_vectors):           # LPStateSpec.groovy:31-48
+    g = reference_vectors["get_leaving"]
+    st = lps.LPState(g["A"], g["b"], [0, 0, 0, 0])
+    for case in g["cases"]:
+        assert st.get_leaving(case["entering"]) == case["leaving"], case
+    with pytest.raises(ValueError):                                # Validate.isTrue -> IllegalArgumentException
+        st.get_leaving(4)
+    with pytest.raises(ValueError):
+        st.get_leaving(-1)
+    st.close()
+
+
+def test_reference_pivot_vectors(lps, reference_vectors):         # LPStateSpec.groovy:50-163
+    for group in reference_vectors["pivot"]:
+        for case in group["cases"]:
+            n, m = len(group["c"]), len(group["b"])
+            names = {s: "x%d" % (i + 1) for s, i in enumerate(group["perm"])}
+            st = lps.LPState(group["A"], group["b"], group["c"], variables=names,
+                             coefficients={v: k for k, v in names.items()})
+            st.pivot(case["entering"], case["leaving"])
+            A, b, c, v, perm = st.read()
+            assert np.array_equal(A, np.array(case["resA"], dtype=float)), (group["source"], case)
+            assert np.array_equal(b, np.array(case["resB"], dtype=float))
+            assert np.array_equal(c, np.array(case["resC"], dtype=float))
+            assert v == case["resV"]
+            assert list(perm) == case["resPerm"]
+            # the reference's name maps after exchangeIndexes (LPState.java:311-320)
+            assert st.variables == {s: "x%d" % (i + 1) for s, i in enumerate(case["resPerm"])}
+            assert st.coefficients == {"x%d" % (i + 1): s for s, i in enumerate(case["resPerm"])}
+            st.close()
+
+
+def test_reference_solve_vectors(lps, reference_vectors):         # LPSolverSpec.groovy:76-111, :151-192
+    for case in reference_vectors["solve"]:
+        form = lps.LPStandardForm(case["A"], case["b"], case["c"], maximize=case["maximize"])
+        solver = lps.LPSolver()
+        if case["status"] == "OPTIMAL":
+            ans = solver.solve(form, restore_order=case.get("restore_order"))
+            assert ans == Decimal(case["answer"]), (case["source"], ans)
+        else:
+            exc = lps.SolutionException if case["status"] == "UNBOUNDED" else lps.LPException
+            with pytest.raises(exc) as ei:
+                solver.solve(form)
+            assert str(ei.value) == case["message"], case["source"]
+            assert solver.last.status == STATUS[case["status"]]
+
+
+def test_reference_initial_infeasible_x0_slot(lps, reference_vectors):   # logs/lp_solver.log:196
+    case = reference_vectors["solve"][2]
+    solver = lps.LPSolver()
+    solver.solve(lps.LPStandardForm(case["A"], case["b"], case["c"], maximize=True), restore_order=[0, 1])
+    assert solver.last.phase1_used and solver.last.x0_slot == 1
+
+
+def test_io_files_first_block_end_to_end(lps, reference_vectors):        # cfg1: io_files/input.txt:1-16 -> 7.000000
+    g = reference_vectors["io_files_first_block"]
+    form = lps.LPInputReader().read_lp(g["text"])
+    assert (form.m, form.n) == (g["m"], g["n"])
+    solver = lps.LPSolver()
+    assert str(solver.solve(form)) == g["objective_text"]
+    x = solver.last.x
+    assert np.all(x >= -1e-12) and np.all(form.A @ x <= form.b + 1e-9) and abs(x.sum() - 7.0) < 1e-9
+
+
+def test_zero_pivot_is_divide_by_zero(lps):
+    st = lps.LPState([[0.0, 1.0], [1.0, 1.0]], [1.0, 2.0], [1.0, 1.0])
+    with pytest.raises(ZeroDivisionError):
+        st.pivot(0, 0)
+    A, b, c, v, perm = st.read()
+    assert np.array_equal(A, [[0.0, 1.0], [1.0, 1.0]]) and list(perm) == [0, 1, 2, 3]   # untouched
+    st.close()
+
+
+# ------------------------------------------------------------------------------------ golden LP cases
+def test_golden_cases_bit_exact_vs_fp64_oracle_and_decimal_tolerance(lps, oracle, decimal_goldens):
+    from linear_programming_solver_amd import _lib
+    for case in decimal_goldens["lp_cases"]:
+        m, n = case["m"], case["n"]
+        A = np.array([float(x) for x in case["A"]]).reshape(m, n)
+        b = np.array([float(x) for x in case["b"]])
+        c = np.array([float(x) for x in case["c"]])
+        want, wst = oracle.solve(A, b, c, maximize=case["maximize"], kind=oracle.FP64)
+        solver = lps.LPSolver()
+        try:
+            solver.solve(lps.LPStandardForm(A, b, c, maximize=case["maximize"]))
+        except (lps.LPException, IndexError):
+            pass
+        got = solver.last
+        name = case["name"]
+        assert got.status == want["status"], name
+        assert got.phase1_used == want["phase1_used"], name
+        assert (got.pivots_phase1, got.pivots_phase2) == (want["pivots1"], want["pivots2"]), name
+        assert got.x0_slot == want["x0_slot"], name
+        assert bits(np.array([got.objective]))[0] == bits(np.array([want["objective"]]))[0], name
+        if got.status == 0:
+            assert list(got.perm) == list(wst.read()[4]), name
+            assert got.objective_text == want["objective_text"], name
+        # against the decimal-15 (reference-semantics) golden: same status and pivot counts; objective in tol
+        if want["trace"].tolist() == case["trace"]:
+            assert got.status == case["status"], name
+            if case["status"] == 0:
+                ref = float(Decimal(case["objective_repr"]))
+                assert abs(got.objective - ref) <= OBJ_TOL * max(1.0, abs(ref)), name
+                assert got.objective_text == case["objective_text"], name
+
+
+def test_final_tableau_bits_after_solve(lps, oracle):
+    """Whole-solve parity of every tableau entry (kept state handle), feasible and infeasible start."""
+    import ctypes as C
+    from linear_programming_solver_amd import _lib
+    rng = np.random.default_rng(11)
+    for trial in range(4):
+        m, n = [(12, 20), (33, 17), (40, 64), (25, 25)][trial]
+        A = rng.integers(-4, 9, size=(m, n)).astype(float) + rng.integers(0, 4, size=(m, n)) / 4.0
+        b = rng.integers(-3 if trial % 2 else 1, 40, size=m).astype(float)
+        c = rng.integers(-2, 6, size=n).astype(float)
+        want, wst = oracle.solve(A, b, c, True, kind=oracle.FP64)
+        L = _lib.lib()
+        opts = _lib.SolveOptions()
+        opts.max_pivots = -1
+        keep = C.c_void_p()
+        opts.keep_state = C.pointer(keep)
+        res = _lib.SolveResult()
+        L.lpx_solve(m, n, A.ctypes.data_as(_lib.dp), n, b.ctypes.data_as(_lib.dp), c.ctypes.data_as(_lib.dp), 1,
+                    C.byref(opts), C.byref(res))
+        assert res.status == want["status"], trial
+        assert (res.pivots_phase1, res.pivots_phase2) == (want["pivots1"], want["pivots2"])
+        assert keep.value
+        fm, fn = C.c_int32(), C.c_int32()
+        L.lpx_state_dims(keep, C.byref(fm), C.byref(fn), None, None)
+        gA = np.zeros((fm.value, fn.value)); gb = np.zeros(fm.value); gc = np.zeros(fn.value)
+        gv = C.c_double(); gp = np.zeros(fm.value + fn.value, dtype=np.int32)
+        L.lpx_state_read(keep, gA.ctypes.data_as(_lib.dp), fn.value, gb.ctypes.data_as(_lib.dp),
+                         gc.ctypes.data_as(_lib.dp), C.byref(gv), gp.ctypes.data_as(_lib.ip))
+        L.lpx_state_destroy(keep)
+        assert (fm.value, fn.value) == (wst.m, wst.n)
+        assert_state_bits_equal((gA, gb, gc, gv.value, gp), wst.read(), "trial %d" % trial)
+
+
+# ------------------------------------------------------------------------------------ step-level parity
+@pytest.mark.parametrize("shape", [(7, 5), (64, 100), (130, 513), (300, 2100), (96, 9000)])
+def test_step_api_every_pivot_bit_exact(lps, oracle, shape):
+    """getEntering / getLeaving / pivot one at a time, full state compared after every pivot.  Shapes cover
+    one strip / several strips / ragged tails of the k_update tiling (n not a multiple of 16, odd m)."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=m * 1000 + n)
+    st = lps.LPState(A, b, c)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for k in range(6):
+        e = st.get_entering()
+        assert e == ref.get_entering()
+        if e < 0:
+            break
+        l = st.get_leaving(e)
+        assert l == ref.get_leaving(e)
+        st.pivot(e, l)
+        assert ref.pivot(e, l) == 0
+        assert_state_bits_equal(st.read(), ref.read(), "after pivot %d of %s" % (k, shape))
+    st.close()
+
+
+@pytest.mark.parametrize("shape", [(50, 80), (257, 300), (200, 1100)])
+def test_device_loop_matches_step_api_and_oracle(lps, oracle, shape):
+    """The fused device-resident loop (select_pivot + update with by-product ratio test) against the oracle
+    after a fixed pivot budget and at optimality."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=7 * m + n)
+    for budget in (1, 2, 17, -1):
+        st = lps.LPState(A, b, c)
+        ref = oracle.State(A, b, c, kind=oracle.FP64)
+        status, pivots, _ = st.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget)
+        assert (status, pivots) == (want["status"], want["pivots"]), (shape, budget)
+        assert_state_bits_equal(st.read(), ref.read(), "budget %d of %s" % (budget, shape))
+        st.close()
+
+
+def test_loop_can_be_resumed(lps, oracle):
+    A, b, c = dense_lp(80, 120, seed=3)
+    st = lps.LPState(A, b, c)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    total = 0
+    for chunk in (3, 5, 1, 40, -1):
+        status, pivots, _ = st.simplex_loop(max_pivots=chunk)
+        want = ref.simplex_loop(max_pivots=chunk)
+        assert (status, pivots) == (want["status"], want["pivots"])
+        total += pivots
+        assert_state_bits_equal(st.read(), ref.read(), "after chunk %d" % chunk)
+    assert status == 0 and total > 40
+    st.close()
+
+
+def test_degenerate_ties_lowest_row_wins(lps, oracle):
+    """Equal ratios everywhere: the leaving row must be the lowest index (strict '<' scan, LPState.java:299)."""
+    m, n = 70, 40
+    A = np.ones((m, n)); b = np.full(m, 3.0); c = np.arange(n, 0, -1).astype(float)
+    st = lps.LPState(A, b, c)
+    assert st.get_entering() == 0 and st.get_leaving(0) == 0
+    status, pivots, _ = st.simplex_loop()
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    want = ref.simplex_loop()
+    assert (status, pivots) == (want["status"], want["pivots"])
+    assert_state_bits_equal(st.read(), ref.read())
+    st.close()
+
+
+def test_unbounded_in_device_loop(lps):
+    st = lps.LPState([[1.0, 0.0]], [1.0], [1.0, 1.0])              # LPSolverSpec.groovy:151-163
+    status, pivots, _ = st.simplex_loop()
+    assert (status, pivots) == (1, 1)
+    st.close()
+
+
+def test_empty_and_tiny_shapes(lps, oracle):
+    st = lps.LPState(np.zeros((0, 3)), [], [0.0, -1.0, 0.0])
+    assert st.get_entering() == -1
+    assert st.simplex_loop()[:2] == (0, 0)
+    st.close()
+    st = lps.LPState([[2.0]], [4.0], [3.0])
+    assert st.simplex_loop()[:2] == (0, 1) and st.v == 6.0
+    st.close()
+
+
+# ------------------------------------------------------------------------------------ cfg2: full solve
+def test_cfg2_full_solve_matches_fp64_oracle_bit_for_bit(lps, oracle):
+    """BASELINE cfg2: dense random LP m=1024 n=2048, full solve.  ~22.7k pivots; the fp64 oracle pins the
+    pivot count, the final basis permutation, the objective bits and position-keyed checksums of A, b, c."""
+    from linear_programming_solver_amd.lp_state import checksum_host
+    m, n = 1024, 2048
+    A, b, c = dense_lp(m, n, seed=1)
+    st = lps.LPState(A, b, c)
+    status, pivots, _ = st.simplex_loop()
+    want, wst = oracle.solve(A, b, c, True, kind=oracle.FP64, threads=8, want_trace=False)
+    assert status == 0 and want["status"] == 0
+    assert pivots == want["pivots2"]
+    wA, wb, wc, wv, wperm = wst.read()
+    assert st.checksum() == checksum_host(wA, wb, wc)
+    _, gb, gc, gv, gperm = st.read(want_A=False)
+    assert list(gperm) == list(wperm)
+    assert bits(np.array([gv]))[0] == bits(np.array([wv]))[0]
+    assert np.array_equal(bits(gb), bits(wb)) and np.array_equal(bits(gc), bits(wc))
+    st.close()
+
+
+def test_cfg2_first_pivots_follow_the_decimal_reference(lps, oracle):
+    """At cfg2 the decimal-15 oracle (reference arithmetic) is too slow for a full solve; it pins the first
+    pivots: same (entering, leaving) sequence, objective within OBJ_TOL."""
+    m, n = 1024, 2048
+    A, b, c = dense_lp(m, n, seed=1)
+    A = np.round(A, 6); b = np.round(b, 6); c = np.round(c, 6)       # <= 15 significant digits: exact decimals
+    K = 6
+    dec = oracle.State(A, b, c, kind=oracle.DEC15)
+    want = dec.simplex_loop(max_pivots=K, threads=8, want_trace=True)
+    f64 = oracle.State(A, b, c, kind=oracle.FP64)
+    w64 = f64.simplex_loop(max_pivots=K, threads=8, want_trace=True)
+    assert want["trace"].tolist() == w64["trace"].tolist()
+    st = lps.LPState(A, b, c)
+    status, pivots, _ = st.simplex_loop(max_pivots=K)
+    assert pivots == K
+    assert_state_bits_equal(st.read(), f64.read())
+    dv = dec.read()[3]
+    assert abs(st.v - dv) <= OBJ_TOL * max(1.0, abs(dv))
+    assert list(st.perm) == list(dec.read()[4])
+    st.close()
