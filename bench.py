@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — simplex pivots/s of the MI355X-native pivot loop, with its HBM roofline and CPU baselines.
+
+    python bench.py --gpus 1 --steps 200 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one simplex pivot (entering scan + ratio test + tableau update + index swap, reference
+LPState.java:274-320, :133-181) of a dense random LP:  A ~ U(0,1), b = (n/4) U(1,2), c ~ U(0,1), maximise
+(SURVEY §8d).  The default workload is BASELINE cfg4 (m=32768, n=16384, 4 GiB fp64 tableau): it is the
+configuration the metric's 1/2/4/8-GPU scaling is quoted on and it fits one GPU, so every N runs the SAME
+job ("scaling": "strong").  At N>1 the tableau is sharded by row blocks, one process per GPU, one RCCL
+all_gather of (8+n) doubles per pivot (linear_programming_solver_amd/sharded.py).
+
+The timed region starts with the tableau resident in HBM (upload excluded).  Rank 0 prints ONE JSON line.
+`roofline.achieved` = 16*m_local*n algorithmic bytes per row-update launch / that kernel's mean duration,
+measured with HIP events on the launch stream inside the timed region.  `cpu_baseline` = the decimal-15
+oracle (the reference's BigDecimal arithmetic, 4 threads as in pivotConcurrently) and `cpu_baseline_fp64` =
+the fp64 oracle on all host cores, both timed here on a bounded row-sample of the same tableau.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "cfg2": (1024, 2048),     # cache-resident; parity config, not a roofline config
+    "cfg3": (8192, 16384),    # 1 GiB tableau, 2.147 GB algorithmic bytes per pivot
+    "cfg4": (32768, 16384),   # 4 GiB tableau, 8.59 GB per pivot; the 1/2/4/8-GPU scaling config
+}
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+CHUNK = 1024
+
+
+def gen_rows(m, n, seed, r0, r1):
+    """Rows [r0, r1) of the global synthetic LP, identical for every sharding (per-1024-row-chunk streams)."""
+    A = np.empty((r1 - r0, n), dtype=np.float64)
+    b = np.empty(r1 - r0, dtype=np.float64)
+    first = r0 // CHUNK
+    last = (r1 - 1) // CHUNK if r1 > r0 else first - 1
+    for ch in range(first, last + 1):
+        rng = np.random.default_rng([seed, 1, ch])
+        rows = min(CHUNK, m - ch * CHUNK)
+        blk = rng.random((rows, n))
+        bb = (n / 4.0) * (1.0 + rng.random(rows))
+        lo, hi = max(r0, ch * CHUNK), min(r1, ch * CHUNK + rows)
+        A[lo - r0:hi - r0] = blk[lo - ch * CHUNK:hi - ch * CHUNK]
+        b[lo - r0:hi - r0] = bb[lo - ch * CHUNK:hi - ch * CHUNK]
+    c = np.random.default_rng([seed, 2]).random(n)
+    return A, b, c
+
+
+def cpu_baselines(A, b, c, m_full, budget_s):
+    """Times the CPU oracle on the first rows of the tableau (bounded sample) and scales to the full height:
+    one pivot costs exactly m*n element updates, so time scales linearly in the number of rows."""
+    from oracle import pyoracle as orc
+    orc.build()
+    out = {}
+    m_s, n = A.shape
+    scale = m_full / float(m_s)
+    cores = os.cpu_count() or 1
+    # fp64, all cores
+    st = orc.State(A, b, c, kind=orc.FP64, with_perm=True)
+    st.simplex_loop(max_pivots=1, threads=cores)  # touch pages / spin up the thread team
+    piv = 8
+    r = st.simplex_loop(max_pivots=piv, threads=cores)
+    per = r["seconds"] / max(1, r["pivots"])
+    out["cpu_baseline_fp64"] = {
+        "value": 1.0 / (per * scale), "unit": "pivots/s", "cores": cores, "kind": "port",
+        "sample": "%d pivots of the fp64 oracle (OpenMP row blocks) on rows 0..%d of the same tableau (%dx%d), "
+                  "per-pivot time scaled x%.3g to m=%d" % (r["pivots"], m_s - 1, m_s, n, scale, m_full)}
+    st.close()
+    # decimal-15 (reference arithmetic), 4 threads = THREAD_AMOUNT of pivotConcurrently (LPState.java:22)
+    rows_d = m_s
+    est_per = 60e-9 * rows_d * n / 2.0  # ~60 ns per element update, ~2x from 4 threads
+    while rows_d > 256 and est_per * 2 > budget_s:
+        rows_d //= 2
+        est_per /= 2
+    Ad, bd = A[:rows_d], b[:rows_d]
+    st = orc.State(Ad, bd, c, kind=orc.DEC15, with_perm=True)
+    r = st.simplex_loop(max_pivots=2, threads=4)
+    per = r["seconds"] / max(1, r["pivots"])
+    scale_d = m_full / float(rows_d)
+    out["cpu_baseline"] = {
+        "value": 1.0 / (per * scale_d), "unit": "pivots/s", "cores": 4, "kind": "port",
+        "sample": "%d pivots of the decimal-15 oracle (BigDecimal/MathContext(15,HALF_UP) semantics, 4 threads "
+                  "with pivotConcurrently's static row partition) on rows 0..%d of the same tableau (%dx%d), "
+                  "per-pivot time scaled x%.3g to m=%d" % (r["pivots"], rows_d - 1, rows_d, n, scale_d, m_full)}
+    st.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=os.environ.get("LPX_BENCH_WORKLOAD", "cfg4"), choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
+    ap.add_argument("--poll-every", type=int, default=32)
+    args = ap.parse_args()
+
+    import torch
+    from linear_programming_solver_amd import LPState, _lib
+    from linear_programming_solver_amd.sharded import DistExchange, HipShardEngine, row_block, sharded_simplex_loop
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed launcher (one process per GPU)" % args.gpus)
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    m, n = WORKLOADS[args.workload]
+    r0, r1 = row_block(m, world, rank)
+    t_gen = time.time()
+    A, b, c = gen_rows(m, n, args.seed, r0, r1)
+    t_gen = time.time() - t_gen
+    K, W = args.steps, args.warmup
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        st = LPState(A, b, c, device=local_rank)
+        status, piv, _ = st.simplex_loop(max_pivots=W)
+        assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
+        st.profile_enable(True)
+        barrier()
+        t0 = time.perf_counter()
+        status, piv, _ = st.simplex_loop(max_pivots=K)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        launches, kernel_ms = st.profile_read()
+        st.profile_enable(False)
+        objective = st.v
+        eng = st
+    else:
+        eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank)
+        ex = DistExchange()
+        status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=W, poll_every=args.poll_every)
+        assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
+        eng.profile_enable(True)
+        barrier()
+        t0 = time.perf_counter()
+        status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=K, poll_every=args.poll_every)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        launches, kernel_ms = eng.profile_read()
+        eng.profile_enable(False)
+        objective = eng.read(want_A=False)[3]
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
+    assert launches == K, "row-update kernel ran %d times for %d pivots" % (launches, K)
+
+    if rank == 0:
+        m_local = r1 - r0
+        alg_bytes = 16.0 * m_local * n                       # every fp64 entry read once, written once
+        avg_ms = kernel_ms / launches
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9         # GB/s of the row-update kernel on this GPU
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (args.workload, world))
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "simplex_pivots_per_sec", "value": K / elapsed, "unit": "pivots/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: dense random LP m=%d n=%d fp64 (A~U(0,1), b=(n/4)U(1,2), c~U(0,1), max), "
+                                   "first-positive entering rule, %d pivots after %d warm-up" % (args.workload, m, n, K, W),
+                       "m": m, "n": n, "seed": args.seed,
+                       "parallelism": "single GPU" if world == 1 else "row-block x%d, 1 all_gather/pivot" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_update", "avg_kernel_ms": avg_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "whole_pivot_frac": 16.0 * m * n * (K / elapsed) / (HBM_PEAK_GBS * 1e9 * world)},
+            "objective_after_timed_region": objective,
+            "host_gen_s": t_gen,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rows_s = min(m, 8192)
+            line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))
+            line["gpu_over_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+            line["gpu_over_cpu_baseline_fp64"] = line["value"] / line["cpu_baseline_fp64"]["value"]
+        print(json.dumps(line), flush=True)
+    if hasattr(eng, "close"):
+        eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

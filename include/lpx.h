@@ -145,8 +145,9 @@ int lpx_shard_propose(lpx_state* s, double* d_candidate);
  * Every rank picks the same winner (min ratio, lowest global row), normalises the pivot row, updates its
  * replicas of c, v, perm and runs the row update on its own block.  No host sync. */
 int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t nranks);
-/* Host poll of the replicated loop state: pivots done so far and LPX_OPTIMAL / LPX_UNBOUNDED /
- * LPX_PIVOT_LIMIT (= still running).  Synchronises the stream. */
+/* Host poll of the replicated loop state: pivots done so far and LPX_RUNNING (-1, loop still live) or
+ * LPX_OPTIMAL / LPX_UNBOUNDED / LPX_PIVOT_LIMIT.  Synchronises the stream. */
+#define LPX_RUNNING (-1)
 int lpx_shard_poll(lpx_state* s, int64_t* pivots_done, int32_t* status);
 
 /* ------------------------------------------------------------------------------------------------

@@ -477,7 +477,7 @@ extern "C" int lpx_shard_poll(lpx_state* s, int64_t* pivots_done, int32_t* statu
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = sync_ctl_to_host(s)) return rc;
   if (pivots_done) *pivots_done = s->h_ctl->pivots;
-  if (status) *status = s->h_ctl->status == lpxk::kRunning ? (int32_t)LPX_PIVOT_LIMIT : s->h_ctl->status;
+  if (status) *status = s->h_ctl->status;  // LPX_RUNNING (-1) while the loop is live
   return 0;
 }
 

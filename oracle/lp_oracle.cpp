@@ -27,7 +27,9 @@ void fill_state(State<T>& st, int m, int n, const double* A, const double* b, co
   typedef Num<T> N;
   st.m = m; st.n = n;
   st.A.resize((size_t)m * n);
-  for (size_t i = 0; i < (size_t)m * n; i++) st.A[i] = N::from_double(A[i]);
+  const int64_t total = (int64_t)m * n;
+#pragma omp parallel for schedule(static) if (total > 100000)
+  for (int64_t i = 0; i < total; i++) st.A[i] = N::from_double(A[i]);
   st.b.resize(m);
   for (int i = 0; i < m; i++) st.b[i] = N::from_double(b[i]);
   st.c.resize(n);
