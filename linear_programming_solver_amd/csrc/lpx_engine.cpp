@@ -88,23 +88,22 @@ static int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
-// Tiling of k_update: enough workgroups to fill 256 CUs several times over, strips as wide as the row
-// allows so the pivot-row slice a workgroup keeps in registers is amortised over rows_per_tile rows.
+// Tiling of k_update.
 static Geometry choose_geometry(int m, int64_t ld) {
+  // Measured on MI355X (profiles/r01_sweep_*.log): one row PAIR x 512 columns per workgroup is fastest at
+  // every size (cfg3 6.3 TB/s vs 5.3 TB/s for 32-row x 2048-column tiles): consecutive workgroups then sweep
+  // the tableau in address order and the tail of the grid is negligible.
   Geometry g{};
-  int U = ld >= 8192 ? 4 : (ld >= 2048 ? 2 : 1);
-  U = env_int("LPX_U", U);
-  if (U != 1 && U != 2 && U != 4) U = 4;
+  int U = env_int("LPX_U", 1);
+  if (U != 1 && U != 2 && U != 4) U = 1;
   g.U = U;
   const int W = 512 * U;
   g.nstrips = (int)((ld + W - 1) / W);
-  const int target_blocks = env_int("LPX_TARGET_BLOCKS", 2048);
-  int64_t R = ((int64_t)m * g.nstrips + target_blocks - 1) / target_blocks;
-  R = std::max<int64_t>(2, std::min<int64_t>(64, R));
+  int R = env_int("LPX_ROWS_PER_TILE", 2);
+  if (R < 2) R = 2;
   if (R & 1) R += 1;  // rows are processed in pairs
-  R = env_int("LPX_ROWS_PER_TILE", (int)R);
-  g.rows_per_tile = (int)R;
-  g.ntiles = m > 0 ? (int)((m + R - 1) / R) : 0;
+  g.rows_per_tile = R;
+  g.ntiles = m > 0 ? (m + R - 1) / R : 0;
   return g;
 }
 
@@ -195,6 +194,8 @@ static void init_ctl(lpx_state* s, double v) {
   c.status = lpxk::kRunning;
   c.track = -1;
   c.max_pivots = -1;
+  c.e_min = INT32_MAX;
+  c.ticket = 0;
 }
 
 static int upload_common(lpx_state* s, const double* A, int64_t lda, const double* b, const double* c, double v,
@@ -334,6 +335,8 @@ static int set_running(lpx_state* s, int64_t max_pivots, int32_t track) {
   s->h_ctl->pivots = 0;
   s->h_ctl->max_pivots = max_pivots;
   s->h_ctl->track = track;
+  s->h_ctl->e_min = INT32_MAX;
+  s->h_ctl->ticket = 0;
   return push_ctl(s);
 }
 

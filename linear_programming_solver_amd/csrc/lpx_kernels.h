@@ -31,6 +31,8 @@ struct LpxCtl {
   int32_t do_update;   // 1 iff k_select_pivot performed a pivot that k_update must apply
   int32_t track;       // slot of the tracked variable (x0 in phase 1), -1 = none  (LPSolver.java:151-155)
   int32_t parity;      // col[parity] receives / holds column e_next
+  int32_t e_min;       // scratch of the pivot-finish kernels: atomicMin target, INT32_MAX when idle
+  int32_t ticket;      // scratch: arrival counter of the pivot-finish workgroups, 0 when idle
   int32_t reserved;
   int64_t pivots;      // pivots performed since lpx_simplex_loop started
   int64_t max_pivots;  // budget for `pivots` (<0: unlimited)

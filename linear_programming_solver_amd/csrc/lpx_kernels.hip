@@ -19,6 +19,8 @@
 
 #include <limits.h>
 
+#include <algorithm>
+
 namespace lpxk {
 
 typedef double d2 __attribute__((ext_vector_type(2)));  // one 16-byte global access per lane
@@ -132,90 +134,115 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const RatioRow* __restr
 // ------------------------------------------------------------------------------------------------ pivot finish
 // Shared tail of k_select_pivot (one GPU) and k_commit (shards): given the winning row (raw, un-normalised)
 // normalise it into prow (LPState.java:139-146), update c, v, perm (:170-180, :311-320), follow the tracked
-// slot (LPSolver.java:151-155) and choose the next entering slot (:274-285).  One workgroup of 1024.
-__device__ __forceinline__ void finish_pivot(const double* raw_row, double raw_b, int e, int l_global,
-                                             double* __restrict__ prow, double* __restrict__ c, int n,
-                                             int64_t ld, int32_t* perm, LpxCtl* ctl, int* sh_int) {
+// slot (LPSolver.java:151-155) and choose the next entering slot (:274-285).
+//
+// Runs on gridDim.x <= 16 workgroups of 1024: every workgroup derives the same (e, l, p) from the same
+// inputs, then owns a grid-strided slice of the columns (one fp64 division per column is the expensive
+// part).  The next entering slot is the minimum over workgroups of "first improving column": each
+// workgroup folds its candidate into ctl->e_min with a returning device-scope atomicMin and then takes a
+// ticket (the ticket's operand depends on the atomic's return value, so the min is performed first); the
+// workgroup that draws the last ticket finalises the replicated loop state.  Nobody spins, so no residency
+// assumption is needed.  ctl fields are only ever written by that last workgroup (or by workgroup 0 on
+// the early exits that all workgroups take alike), after every workgroup has read what it needs.
+__device__ __forceinline__ void finish_pivot(const double* __restrict__ raw_row, double raw_b, int e,
+                                             int l_global, double ratio, double* __restrict__ prow,
+                                             double* __restrict__ c, int n, int64_t ld, int32_t* perm,
+                                             LpxCtl* ctl, int* sh_int) {
   const double p = raw_row[e];
   if (p == 0.0) {  // ArithmeticException in the reference (BigDecimal.divide by zero), :139
-    if (threadIdx.x == 0) { ctl->status = 8 /* LPX_DIVIDE_BY_ZERO */; ctl->do_update = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->status = 8 /* LPX_DIVIDE_BY_ZERO */; ctl->do_update = 0; }
     return;
   }
-  const double pc = c[e];
+  const double pc = c[e];  // c[e] itself is rewritten only by the finalising workgroup
   const double bl = __ddiv_rn(raw_b, p);                                           // :146
   const double inv_p = __ddiv_rn(1.0, p);                                          // :139
   int first_pos = INT_MAX;
-  __syncthreads();  // every thread has read c[e] before anyone overwrites it
-  for (int j = threadIdx.x; j < (int)ld; j += blockDim.x) {
-    double pr, cn;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < (int)ld; j += gridDim.x * blockDim.x) {
     if (j == e) {
-      pr = inv_p;
-      cn = -__ddiv_rn(pc, p);                                                      // :172
+      prow[j] = inv_p;
     } else {
       const double x = (j < n) ? raw_row[j] : 0.0;
-      pr = __ddiv_rn(x, p);                                                        // :144
-      cn = __dsub_rn(c[j], __dmul_rn(pc, pr));                                     // :177
+      const double pr = __ddiv_rn(x, p);                                           // :144
+      const double cn = __dsub_rn(c[j], __dmul_rn(pc, pr));                        // :177
+      prow[j] = pr;
+      c[j] = cn;
+      if (j < n && cn > kEps && first_pos == INT_MAX) first_pos = j;  // j ascends per thread
     }
-    prow[j] = pr;
-    c[j] = cn;
-    if (j < n && cn > kEps && first_pos == INT_MAX) first_pos = j;
   }
   first_pos = block_min_int(first_pos, sh_int);
   if (threadIdx.x == 0) {
-    ctl->v = __dadd_rn(ctl->v, __dmul_rn(bl, pc));                                 // :171
-    const int32_t t = perm[e];                                                     // exchangeIndexes :311-320
-    perm[e] = perm[n + l_global];
-    perm[n + l_global] = t;
-    if (ctl->track >= 0) {                                                         // LPSolver.java:151-155
-      if (e == ctl->track) ctl->track = l_global + n;
-      else if (l_global + n == ctl->track) ctl->track = e;
+    int old = 0;
+    if (first_pos != INT_MAX) old = atomicMin(&ctl->e_min, first_pos);
+    int inc = 1;
+    asm volatile("" : "+v"(inc) : "v"(old));  // the ticket below is issued after the min has returned
+    const int ticket = atomicAdd(&ctl->ticket, inc);
+    if (ticket == (int)gridDim.x - 1) {
+      int e_min = atomicMin(&ctl->e_min, INT_MAX);  // returning atomic: the folded minimum
+      const double ce_new = -__ddiv_rn(pc, p);                                     // :172
+      c[e] = ce_new;
+      if (e < n && ce_new > kEps) e_min = min(e_min, e);  // possible on forced / degenerate pivots only
+      ctl->v = __dadd_rn(ctl->v, __dmul_rn(bl, pc));                               // :171
+      const int32_t t = perm[e];                                                   // exchangeIndexes :311-320
+      perm[e] = perm[n + l_global];
+      perm[n + l_global] = t;
+      if (ctl->track >= 0) {                                                       // LPSolver.java:151-155
+        if (e == ctl->track) ctl->track = l_global + n;
+        else if (l_global + n == ctl->track) ctl->track = e;
+      }
+      ctl->p = p;
+      ctl->bl = bl;
+      ctl->pc = pc;
+      ctl->ratio = ratio;
+      ctl->e_cur = e;
+      ctl->l = l_global;
+      ctl->e_next = (e_min == INT_MAX) ? -1 : e_min;
+      if (e_min == INT_MAX) ctl->status = 0 /* LPX_OPTIMAL: reached after k_update applies this pivot */;
+      ctl->parity ^= 1;  // k_update reads col[parity^1] (column e_cur) and fills col[parity] (column e_next)
+      ctl->pivots += 1;
+      ctl->do_update = 1;
+      atomicExch(&ctl->e_min, INT_MAX);
+      atomicExch(&ctl->ticket, 0);
     }
-    ctl->p = p;
-    ctl->bl = bl;
-    ctl->pc = pc;
-    ctl->e_cur = e;
-    ctl->l = l_global;
-    ctl->e_next = (first_pos == INT_MAX) ? -1 : first_pos;
-    if (first_pos == INT_MAX) ctl->status = 0 /* LPX_OPTIMAL: reached after k_update applies this pivot */;
-    ctl->parity ^= 1;  // k_update reads col[parity^1] (column e_cur) and fills col[parity] (column e_next)
-    ctl->pivots += 1;
-    ctl->do_update = 1;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ k_select_pivot
-__global__ __launch_bounds__(1024) void k_select_pivot(const double* A, int64_t ld, int n, int m_global,
-                                                       const double* b, double* c, double* prow,
-                                                       const RatioRow* partial, int nparts, int32_t* perm,
-                                                       LpxCtl* ctl, int forced_e, int forced_l) {
+__global__ __launch_bounds__(1024) void k_select_pivot(const double* __restrict__ A, int64_t ld, int n,
+                                                       int m_global, const double* __restrict__ b, double* c,
+                                                       double* prow, const RatioRow* __restrict__ partial,
+                                                       int nparts, int32_t* perm, LpxCtl* ctl, int forced_e,
+                                                       int forced_l) {
   __shared__ RatioRow sh_rr[16];
   __shared__ int sh_int[16];
+  const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
   if (ctl->status != kRunning) {
-    if (threadIdx.x == 0) ctl->do_update = 0;
+    if (writer) ctl->do_update = 0;
     return;
   }
   int e, l;
+  double ratio = 0.0;
   if (forced_l >= 0) {  // pivot(entering, leaving) of the step API
     e = forced_e;
     l = forced_l;
   } else {
     e = ctl->e_next;
+    const int64_t pivots = ctl->pivots, max_pivots = ctl->max_pivots;
     RatioRow best = rr_none();
     for (int k = threadIdx.x; k < nparts; k += blockDim.x) best = rr_min(best, partial[k]);
     best = rr_block_min(best, sh_rr);
     l = (best.ratio < kInf) ? best.row : -1;
+    ratio = best.ratio;
     if (l < 0) {  // getLeaving() == -1: unbounded (LPSolver.java:103-106 / :147-150)
-      if (threadIdx.x == 0) { ctl->status = 1 /* LPX_UNBOUNDED */; ctl->do_update = 0; ctl->l = -1; ctl->ratio = best.ratio; }
+      if (writer) { ctl->status = 1 /* LPX_UNBOUNDED */; ctl->do_update = 0; ctl->l = -1; ctl->ratio = best.ratio; }
       return;
     }
-    if (ctl->max_pivots >= 0 && ctl->pivots >= ctl->max_pivots) {
-      if (threadIdx.x == 0) { ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; }
+    if (max_pivots >= 0 && pivots >= max_pivots) {
+      if (writer) { ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; }
       return;
     }
-    if (threadIdx.x == 0) ctl->ratio = best.ratio;
   }
   (void)m_global;
-  finish_pivot(A + (int64_t)l * ld, b[l], e, l, prow, c, n, ld, perm, ctl, sh_int);
+  finish_pivot(A + (int64_t)l * ld, b[l], e, l, ratio, prow, c, n, ld, perm, ctl, sh_int);
 }
 
 // ------------------------------------------------------------------------------------------------ k_update
@@ -375,6 +402,7 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ A, int64_t 
 
 // ------------------------------------------------------------------------------------------------ shards
 // k_propose: fold this shard's partials into its candidate and pack {header, raw row} for the all-gather.
+// Every workgroup reduces the partials alike; workgroup 0 writes the header, all copy a slice of the row.
 __global__ __launch_bounds__(1024) void k_propose(const double* __restrict__ A, int64_t ld, int n, int row0,
                                                   int m_local, const double* __restrict__ b,
                                                   const RatioRow* __restrict__ partial, int nparts,
@@ -388,7 +416,7 @@ __global__ __launch_bounds__(1024) void k_propose(const double* __restrict__ A, 
   }
   const bool have = best.ratio < kInf;
   const int lr = have ? best.row - row0 : -1;
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     cand[0] = (st == kRunning) ? 0.0 : (double)(st + 1);
     cand[1] = (double)ctl->e_next;
     cand[2] = best.ratio;
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(1024) void k_propose(const double* __restrict__ A, 
   }
   if (have) {
     const double* row = A + (int64_t)lr * ld;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) cand[8 + j] = row[j];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) cand[8 + j] = row[j];
   }
   (void)m_local;
 }
@@ -408,10 +436,13 @@ __global__ __launch_bounds__(1024) void k_commit(const double* __restrict__ gath
                                                  int64_t ld, int m_global, double* c, double* prow,
                                                  int32_t* perm, LpxCtl* ctl) {
   __shared__ int sh_int[16];
+  const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
   if (ctl->status != kRunning) {
-    if (threadIdx.x == 0) ctl->do_update = 0;
+    if (writer) ctl->do_update = 0;
     return;
   }
+  const int64_t pivots = ctl->pivots, max_pivots = ctl->max_pivots;
+  const int e = ctl->e_next;
   const int64_t rec = 8 + (int64_t)n;
   RatioRow best = rr_none();
   int win = -1;
@@ -424,18 +455,16 @@ __global__ __launch_bounds__(1024) void k_commit(const double* __restrict__ gath
     }
   }
   if (win < 0 || !(best.ratio < kInf)) {
-    if (threadIdx.x == 0) { ctl->status = 1 /* LPX_UNBOUNDED */; ctl->do_update = 0; ctl->l = -1; ctl->ratio = best.ratio; }
+    if (writer) { ctl->status = 1 /* LPX_UNBOUNDED */; ctl->do_update = 0; ctl->l = -1; ctl->ratio = best.ratio; }
     return;
   }
-  if (ctl->max_pivots >= 0 && ctl->pivots >= ctl->max_pivots) {
-    if (threadIdx.x == 0) { ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; }
+  if (max_pivots >= 0 && pivots >= max_pivots) {
+    if (writer) { ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; }
     return;
   }
-  const int e = ctl->e_next;
-  if (threadIdx.x == 0) ctl->ratio = best.ratio;
   const double* h = gathered + win * rec;
   (void)m_global;
-  finish_pivot(h + 8, h[4], e, best.row, prow, c, n, ld, perm, ctl, sh_int);
+  finish_pivot(h + 8, h[4], e, best.row, best.ratio, prow, c, n, ld, perm, ctl, sh_int);
 }
 
 // ------------------------------------------------------------------------------------------------ phase 1 helpers
@@ -562,9 +591,12 @@ void launch_reduce_partials(const Buffers& B, const Geometry& g, hipStream_t s) 
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, s, B.partial, g.ntiles, B.ctl);
 }
 
+// workgroups of the pivot-finish kernels: one column per thread up to 16 workgroups
+static int finish_blocks(int64_t ld) { return (int)std::max<int64_t>(1, std::min<int64_t>(16, (ld + 1023) / 1024)); }
+
 void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& g, int forced_e, int forced_l,
                          hipStream_t s) {
-  hipLaunchKernelGGL(k_select_pivot, dim3(1), dim3(1024), 0, s, B.A, B.ld, n, m_global, B.b, B.c, B.prow,
+  hipLaunchKernelGGL(k_select_pivot, dim3(finish_blocks(B.ld)), dim3(1024), 0, s, B.A, B.ld, n, m_global, B.b, B.c, B.prow,
                      B.partial, g.ntiles, B.perm, B.ctl, forced_e, forced_l);
 }
 
@@ -586,12 +618,12 @@ void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometr
 
 void launch_propose(const Buffers& B, int n, int row0, int m_local, const Geometry& g, double* d_candidate,
                     hipStream_t s) {
-  hipLaunchKernelGGL(k_propose, dim3(1), dim3(1024), 0, s, B.A, B.ld, n, row0, m_local, B.b, B.partial,
+  hipLaunchKernelGGL(k_propose, dim3(finish_blocks(B.ld)), dim3(1024), 0, s, B.A, B.ld, n, row0, m_local, B.b, B.partial,
                      g.ntiles, B.ctl, d_candidate);
 }
 
 void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, hipStream_t s) {
-  hipLaunchKernelGGL(k_commit, dim3(1), dim3(1024), 0, s, d_gathered, nranks, n, B.ld, m_global, B.c, B.prow,
+  hipLaunchKernelGGL(k_commit, dim3(finish_blocks(B.ld)), dim3(1024), 0, s, d_gathered, nranks, n, B.ld, m_global, B.c, B.prow,
                      B.perm, B.ctl);
 }
 
