@@ -57,6 +57,19 @@ def gen_rows(m, n, seed, r0, r1):
     return A, b, c
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask and cgroup quota, not the host's core count
+    (a GPU box gives one job a 16-CPU share of a much larger host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("LPX_BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baselines(A, b, c, m_full, budget_s):
     """Times the CPU oracle on the first rows of the tableau (bounded sample) and scales to the full height:
     one pivot costs exactly m*n element updates, so time scales linearly in the number of rows."""
@@ -65,8 +78,8 @@ def cpu_baselines(A, b, c, m_full, budget_s):
     out = {}
     m_s, n = A.shape
     scale = m_full / float(m_s)
-    cores = os.cpu_count() or 1
-    # fp64, all cores
+    cores = host_cores()
+    # fp64, all cores of this process's CPU share
     st = orc.State(A, b, c, kind=orc.FP64, with_perm=True)
     st.simplex_loop(max_pivots=1, threads=cores)  # touch pages / spin up the thread team
     piv = 8
@@ -107,6 +120,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--poll-every", type=int, default=32)
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="bracket every N-th row-update launch of the timed region with a HIP event pair "
+                         "(an event pair costs ~3 us of stream time; 1 = every launch, 0 = none)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the row-block shard engine + the torch.distributed collective even at N=1")
     args = ap.parse_args()
 
     import torch
@@ -124,10 +142,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     m, n = WORKLOADS[args.workload]
     r0, r1 = row_block(m, world, rank)
@@ -141,11 +162,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if not sharded:
         st = LPState(A, b, c, device=local_rank)
         status, piv, _ = st.simplex_loop(max_pivots=W)
         assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
-        st.profile_enable(True)
+        st.profile_enable(args.event_every)
         barrier()
         t0 = time.perf_counter()
         status, piv, _ = st.simplex_loop(max_pivots=K)
@@ -160,7 +181,7 @@ def main():
         ex = DistExchange()
         status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=W, poll_every=args.poll_every)
         assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
-        eng.profile_enable(True)
+        eng.profile_enable(args.event_every)
         barrier()
         t0 = time.perf_counter()
         status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=K, poll_every=args.poll_every)
@@ -173,12 +194,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
-    assert launches == K, "row-update kernel ran %d times for %d pivots" % (launches, K)
+    expect = 0 if args.event_every <= 0 else (K + args.event_every - 1) // args.event_every
+    assert launches == expect, "sampled %d row-update launches, expected %d" % (launches, expect)
 
     if rank == 0:
         m_local = r1 - r0
         alg_bytes = 16.0 * m_local * n                       # every fp64 entry read once, written once
-        avg_ms = kernel_ms / launches
+        avg_ms = kernel_ms / launches if launches else float("nan")
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9         # GB/s of the row-update kernel on this GPU
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (args.workload, world))
@@ -195,10 +217,11 @@ def main():
             "config": {"workload": "%s: dense random LP m=%d n=%d fp64 (A~U(0,1), b=(n/4)U(1,2), c~U(0,1), max), "
                                    "first-positive entering rule, %d pivots after %d warm-up" % (args.workload, m, n, K, W),
                        "m": m, "n": n, "seed": args.seed,
-                       "parallelism": "single GPU" if world == 1 else "row-block x%d, 1 all_gather/pivot" % world},
+                       "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_update", "avg_kernel_ms": avg_ms, "launches": launches,
+                         "kernel": "k_update", "avg_kernel_ms": avg_ms, "launches_sampled": launches,
+                         "launches": K,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "whole_pivot_frac": 16.0 * m * n * (K / elapsed) / (HBM_PEAK_GBS * 1e9 * world)},
             "objective_after_timed_region": objective,

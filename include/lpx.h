@@ -119,8 +119,9 @@ int lpx_state_dims(const lpx_state* s, int32_t* m_local, int32_t* n, int32_t* ro
 int lpx_state_checksum(lpx_state* s, uint64_t out[3]);
 
 /* Per-kernel timing of the row-update kernel with HIP events on the handle's stream (bench.py's
- * roofline figure).  enable=1 starts collecting; lpx_profile_read returns launches and total ms since
- * enable and resets the counters. */
+ * roofline figure).  enable = N > 0 brackets every N-th row-update launch with an event pair (N = 1: all;
+ * an event pair costs a few microseconds of stream time, so bench.py samples sparsely); 0 stops.
+ * lpx_profile_read returns the number of sampled launches and their total ms since enable, and resets. */
 int lpx_profile_enable(lpx_state* s, int enable);
 int lpx_profile_read(lpx_state* s, int64_t* launches, double* total_ms);
 
@@ -145,6 +146,9 @@ int lpx_shard_propose(lpx_state* s, double* d_candidate);
  * Every rank picks the same winner (min ratio, lowest global row), normalises the pivot row, updates its
  * replicas of c, v, perm and runs the row update on its own block.  No host sync. */
 int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t nranks);
+/* The decision step of lpx_shard_commit without the row update: issued as the LAST step of a budgeted run
+ * (after max_pivots commits), where it can only report LPX_UNBOUNDED or LPX_PIVOT_LIMIT.  No host sync. */
+int lpx_shard_probe(lpx_state* s, const double* d_gathered, int32_t nranks);
 /* Host poll of the replicated loop state: pivots done so far and LPX_RUNNING (-1, loop still live) or
  * LPX_OPTIMAL / LPX_UNBOUNDED / LPX_PIVOT_LIMIT.  Synchronises the stream. */
 #define LPX_RUNNING (-1)

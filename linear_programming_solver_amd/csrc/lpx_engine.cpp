@@ -74,7 +74,8 @@ struct lpx_state {
   LpxCtl* h_ctl = nullptr;          // pinned mirror
   unsigned long long* d_sum = nullptr;
   // row-update profiling (HIP events on `stream`)
-  bool prof = false;
+  int prof = 0;                     // 0 = off, N = bracket every N-th row-update launch with events
+  int64_t prof_seq = 0;
   std::vector<hipEvent_t> ev;       // pairs
   size_t ev_used = 0;
   int64_t prof_launches = 0;
@@ -267,7 +268,7 @@ extern "C" int lpx_state_dims(const lpx_state* s, int32_t* m_local, int32_t* n, 
 
 // ------------------------------------------------------------------------------------------------ launches
 static int launch_update_profiled(lpx_state* s) {
-  if (s->prof) {
+  if (s->prof > 0 && (s->prof_seq++ % s->prof) == 0) {
     if (s->ev_used + 2 > s->ev.size()) {
       for (int k = 0; k < 512; k++) {
         hipEvent_t e;
@@ -303,7 +304,8 @@ extern "C" int lpx_profile_enable(lpx_state* s, int enable) {
   if (!s) return fail(LPX_BAD_ARGUMENT, "NULL state");
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = drain_profile(s)) return rc;
-  s->prof = enable != 0;
+  s->prof = enable > 0 ? enable : 0;
+  s->prof_seq = 0;
   s->prof_launches = 0;
   s->prof_ms = 0.0;
   return 0;
@@ -461,6 +463,16 @@ extern "C" int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t 
   HIP_TRY(hipSetDevice(s->device));
   lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, s->stream);
   if (int rc = launch_update_profiled(s)) return rc;
+  return 0;
+}
+
+// Same decision step as lpx_shard_commit but without the row update: the driver issues it as the LAST step
+// of a budgeted run, where the only possible outcomes are UNBOUNDED / PIVOT_LIMIT (budget exhausted).
+extern "C" int lpx_shard_probe(lpx_state* s, const double* d_gathered, int32_t nranks) {
+  if (!s || !d_gathered || nranks < 1) return fail(LPX_BAD_ARGUMENT, "lpx_shard_probe: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, s->stream);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 

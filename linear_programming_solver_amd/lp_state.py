@@ -139,8 +139,9 @@ class LPState:
             raise_for_status(rc)
         return int(out[0]), int(out[1]), int(out[2])
 
-    def profile_enable(self, on=True):
-        rc = self._L.lpx_profile_enable(self._h, 1 if on else 0)
+    def profile_enable(self, every=1):
+        """Bracket every `every`-th row-update launch with HIP events (0/False: off)."""
+        rc = self._L.lpx_profile_enable(self._h, int(every))
         if rc:
             raise_for_status(rc)
 

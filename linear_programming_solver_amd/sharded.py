@@ -88,8 +88,9 @@ class HipShardEngine:
         if rc:
             raise_for_status(rc)
 
-    def commit(self):
-        rc = self._L.lpx_shard_commit(self._h, C.c_void_p(self.gathered.data_ptr()), self.nranks)
+    def commit(self, probe_only=False):
+        fn = self._L.lpx_shard_probe if probe_only else self._L.lpx_shard_commit
+        rc = fn(self._h, C.c_void_p(self.gathered.data_ptr()), self.nranks)
         if rc:
             raise_for_status(rc)
 
@@ -121,8 +122,8 @@ class HipShardEngine:
             raise_for_status(rc)
         return int(out[0]), int(out[1]), int(out[2])
 
-    def profile_enable(self, on=True):
-        self._L.lpx_profile_enable(self._h, 1 if on else 0)
+    def profile_enable(self, every=1):
+        self._L.lpx_profile_enable(self._h, int(every))
 
     def profile_read(self):
         n, ms = C.c_int64(), C.c_double()
@@ -178,12 +179,14 @@ def sharded_simplex_loop(engines, exchange, max_pivots=-1, track_slot=-1, poll_e
         if max_pivots >= 0:
             # max_pivots pivots need max_pivots+1 select steps: the last one only reports LIMIT / UNBOUNDED
             burst = max(0, min(burst, max_pivots + 1 - issued))
-        for _ in range(burst):
+        for k in range(burst):
+            # step number max_pivots (0-based) is the budget probe: it cannot pivot, so it skips the row update
+            probe = max_pivots >= 0 and issued + k == max_pivots
             for e in engines:
                 e.propose()
             exchange.all_gather(engines)
             for e in engines:
-                e.commit()
+                e.commit(probe_only=probe)
         issued += burst
         polled = [e.poll() for e in engines]
         pivots, status = polled[0]

@@ -54,7 +54,7 @@ class NumpyShardEngine:
             cand[2], cand[3], cand[4] = ratio[i], self.row0 + i, self.b[i]
             cand[HEADER:] = self.A[i]
 
-    def commit(self):
+    def commit(self, probe_only=False):
         if self.status != RUNNING:
             return
         rec = HEADER + self.n
@@ -69,6 +69,7 @@ class NumpyShardEngine:
         if 0 <= self.max_pivots <= self.pivots:
             self.status = PIVOT_LIMIT
             return
+        assert not probe_only, "the budget probe step must never be able to pivot"
         e, l = self.e_next, best[1]
         raw, raw_b = g[win, HEADER:].copy(), g[win, 4]
         p = raw[e]
