@@ -127,6 +127,12 @@ def main():
                     help="use the row-block shard engine + the torch.distributed collective even at N=1")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout: RCCL prints a version banner to fd 1 at init, so everything
+    # else (C-level output included) is routed to stderr and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from linear_programming_solver_amd import LPState, _lib
     from linear_programming_solver_amd.sharded import DistExchange, HipShardEngine, row_block, sharded_simplex_loop
@@ -232,7 +238,7 @@ def main():
             line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))
             line["gpu_over_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
             line["gpu_over_cpu_baseline_fp64"] = line["value"] / line["cpu_baseline_fp64"]["value"]
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if hasattr(eng, "close"):
         eng.close()
     if dist is not None:
