@@ -348,3 +348,72 @@ def test_shard_kernels_on_one_gpu_match_oracle(lps, oracle, nshards, shape, budg
         assert np.array_equal(bits(gb), bits(wb[r0:r0 + e.m_local]))
         assert np.array_equal(bits(gc), bits(wc)) and gv == wv and list(gperm) == list(wperm)
         e.close()
+
+
+# ------------------------------------------------------------------------------------ cfg5: phase 1, degenerate
+def test_cfg5_degenerate_phase1_basis_bit_exact_vs_reference_semantics(lps, oracle):
+    """BASELINE cfg5: m = n = 4096 integer LP with negative right-hand sides (auxiliary-LP phase 1, forced
+    first pivot, x0 tracking, column drop + objective restore) and massive ratio ties.  The basis permutation,
+    pivot counts, x0's final slot and the objective text must equal the committed decimal-15 golden (the
+    reference's BigDecimal semantics, tests/golden/gen_cfg5.py) exactly, and the whole final state must equal
+    the fp64 oracle bit for bit."""
+    import ctypes as C
+    import json
+    import os
+    from linear_programming_solver_amd import _lib
+    from linear_programming_solver_amd.lp_state import checksum_host
+    from tests.golden.gen_cfg5 import make_cfg5
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cfg5_golden_4096x4096.json")))
+    m, n = gold["m"], gold["n"]
+    A, b, c = make_cfg5(m, n, gold["seed"])
+    L = _lib.lib()
+    opts = _lib.SolveOptions()
+    opts.max_pivots = -1
+    keep = C.c_void_p()
+    opts.keep_state = C.pointer(keep)
+    perm = np.zeros(n + m, dtype=np.int32)
+    opts.perm_out = perm.ctypes.data_as(_lib.ip)
+    res = _lib.SolveResult()
+    rc = L.lpx_solve(m, n, A.ctypes.data_as(_lib.dp), n, b.ctypes.data_as(_lib.dp), c.ctypes.data_as(_lib.dp), 1,
+                     C.byref(opts), C.byref(res))
+    assert rc == 0 and res.status == gold["status"] == 0
+    assert res.phase1_used == 1
+    assert (res.pivots_phase1, res.pivots_phase2) == (gold["pivots_phase1"], gold["pivots_phase2"])
+    assert res.x0_slot == gold["x0_slot"]
+    assert res.objective_text.decode() == gold["objective_text"]
+    first_diff = next((i for i in range(n + m) if perm[i] != gold["perm"][i]), None)
+    assert first_diff is None, "basis permutation diverges from the decimal reference at slot %r" % first_diff
+    # whole final state against the fp64 oracle
+    want, wst = oracle.solve(A, b, c, True, kind=oracle.FP64, threads=8, want_trace=False)
+    wA, wb, wc, wv, wperm = wst.read()
+    out = (C.c_uint64 * 3)()
+    assert L.lpx_state_checksum(keep, out) == 0
+    assert (int(out[0]), int(out[1]), int(out[2])) == checksum_host(wA, wb, wc)
+    assert bits(np.array([res.objective]))[0] == bits(np.array([want["objective"]]))[0]
+    assert list(perm) == list(wperm)
+    L.lpx_state_destroy(keep)
+
+
+def test_get_dual_on_device(lps, reference_vectors):                # LPStandardFormSpec.groovy:6-25
+    g = reference_vectors["get_dual"]
+    names = {i: "x%d" % (i + 1) for i in range(4)}
+    form = lps.LPStandardForm(g["A"], g["b"], g["c"], names, {v: k for k, v in names.items()}, 3, 4, g["maximize"])
+    dual = form.get_dual()
+    assert dual.A.tolist() == g["dualA"]
+    assert dual.b.tolist() == g["c"] and dual.c.tolist() == g["b"]
+    assert (dual.m, dual.n, dual.maximize) == (g["dual_m"], g["dual_n"], g["dual_maximize"])
+    rng = np.random.default_rng(0)
+    big = rng.random((300, 1000))
+    d2 = lps.LPStandardForm(big, np.ones(300), np.ones(1000)).get_dual()
+    assert np.array_equal(d2.A, big.T)
+
+
+def test_solution_vector_and_names_after_solve(lps, oracle):
+    """x* (the reference's commented-out printSolution, LPSolver.java:344-374) is feasible and attains v."""
+    A, b, c = dense_lp(60, 90, seed=21)
+    solver = lps.LPSolver()
+    ans = solver.solve(lps.LPStandardForm(A, b, c, maximize=True))
+    x = solver.last.x
+    assert np.all(x >= 0) and np.all(A @ x <= b * (1 + 1e-12) + 1e-9)
+    assert abs(c @ x - solver.last.objective) <= 1e-9 * max(1, abs(solver.last.objective))
+    assert abs(float(ans) - solver.last.objective) <= 5e-7
