@@ -168,8 +168,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_up = time.perf_counter()
     if not sharded:
         st = LPState(A, b, c, device=local_rank)
+        t_up = time.perf_counter() - t_up
         status, piv, _ = st.simplex_loop(max_pivots=W)
         assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
         st.profile_enable(args.event_every)
@@ -184,6 +186,7 @@ def main():
         eng = st
     else:
         eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank)
+        t_up = time.perf_counter() - t_up
         ex = DistExchange()
         status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=W, poll_every=args.poll_every)
         assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
@@ -232,6 +235,7 @@ def main():
                          "whole_pivot_frac": 16.0 * m * n * (K / elapsed) / (HBM_PEAK_GBS * 1e9 * world)},
             "objective_after_timed_region": objective,
             "host_gen_s": t_gen,
+            "host_upload_s": t_up,   # hipMalloc + PCIe upload of this rank's tableau; outside the timed region
         }
         if world == 1 and not args.no_cpu_baseline:
             rows_s = min(m, 8192)
