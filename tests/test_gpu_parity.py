@@ -514,3 +514,78 @@ def test_cfg4_size_properties_and_sharding_invariance(lps):
     assert np.array_equal(bits(sc), bits(single[2])) and sv == single[3] and list(sperm) == list(single[4])
     for e in engines:
         e.close()
+
+
+def test_create_from_device_pointers(lps, oracle):
+    """lpx_state_create_from_device: inputs already resident in HBM (torch CUDA tensors here)."""
+    import ctypes as C
+    import torch
+    from linear_programming_solver_amd import _lib
+    m, n = 40, 70
+    A, b, c = dense_lp(m, n, seed=77)
+    dA = torch.from_numpy(A).cuda(); db = torch.from_numpy(b).cuda(); dc = torch.from_numpy(c).cuda()
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    h = C.c_void_p()
+    rc = L.lpx_state_create_from_device(m, n, C.c_void_p(dA.data_ptr()), n, C.c_void_p(db.data_ptr()),
+                                        C.c_void_p(dc.data_ptr()), 0.0, None, 0, m, 0, C.byref(h))
+    assert rc == 0, _lib.last_error()
+    piv, st = C.c_int64(), C.c_int32()
+    assert L.lpx_simplex_loop(h, -1, C.byref(piv), C.byref(st), None) == 0
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    want = ref.simplex_loop()
+    assert (st.value, piv.value) == (want["status"], want["pivots"])
+    gA = np.zeros((m, n)); gb = np.zeros(m); gc = np.zeros(n); gv = C.c_double(); gp = np.zeros(n + m, dtype=np.int32)
+    L.lpx_state_read(h, gA.ctypes.data_as(_lib.dp), n, gb.ctypes.data_as(_lib.dp), gc.ctypes.data_as(_lib.dp),
+                     C.byref(gv), gp.ctypes.data_as(_lib.ip))
+    assert_state_bits_equal((gA, gb, gc, gv.value, gp), ref.read())
+    assert np.array_equal(dA.cpu().numpy(), A)          # the caller's device buffers are never written
+    L.lpx_state_destroy(h)
+
+
+def test_two_handles_from_two_host_threads(lps, oracle):
+    """Different handles may be driven from different host threads (include/lpx.h threading contract)."""
+    import threading
+    results = {}
+
+    def work(k):
+        A, b, c = dense_lp(90 + k, 150, seed=500 + k)
+        st = lps.LPState(A, b, c)
+        status, pivots, _ = st.simplex_loop()
+        results[k] = (status, pivots, st.read())
+        st.close()
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(3):
+        A, b, c = dense_lp(90 + k, 150, seed=500 + k)
+        ref = oracle.State(A, b, c, kind=oracle.FP64)
+        want = ref.simplex_loop()
+        assert results[k][:2] == (want["status"], want["pivots"])
+        assert_state_bits_equal(results[k][2], ref.read(), "thread %d" % k)
+
+
+def test_leading_dimension_and_lda_validation(lps):
+    import ctypes as C
+    from linear_programming_solver_amd import _lib
+    L = _lib.lib()
+    m, n, lda = 5, 7, 11
+    rng = np.random.default_rng(4)
+    buf = rng.random((m, lda)); b = np.ones(m) * 3; c = rng.random(n)
+    h = C.c_void_p()
+    assert L.lpx_state_create(m, n, buf.ctypes.data_as(_lib.dp), lda, b.ctypes.data_as(_lib.dp),
+                              c.ctypes.data_as(_lib.dp), 0.0, None, 0, m, 0, C.byref(h)) == 0
+    out = np.full((m, lda), -7.0)
+    L.lpx_state_read(h, out.ctypes.data_as(_lib.dp), lda, None, None, None, None)
+    assert np.array_equal(out[:, :n], buf[:, :n]) and np.all(out[:, n:] == -7.0)   # only n columns per row touched
+    L.lpx_state_destroy(h)
+    h2 = C.c_void_p()
+    assert L.lpx_state_create(m, n, buf.ctypes.data_as(_lib.dp), n - 1, b.ctypes.data_as(_lib.dp),
+                              c.ctypes.data_as(_lib.dp), 0.0, None, 0, m, 0, C.byref(h2)) == _lib.BAD_ARGUMENT
+    assert L.lpx_state_create(-1, n, None, n, None, c.ctypes.data_as(_lib.dp), 0.0, None, 0, 0, 0,
+                              C.byref(h2)) == _lib.BAD_ARGUMENT
+    assert L.lpx_state_create(m, n, buf.ctypes.data_as(_lib.dp), lda, b.ctypes.data_as(_lib.dp),
+                              c.ctypes.data_as(_lib.dp), 0.0, None, 0, m, 99, C.byref(h2)) == _lib.BAD_ARGUMENT
