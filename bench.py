@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket every N-th row-update launch of the timed region with a HIP event pair "
                          "(an event pair costs ~3 us of stream time; 1 = every launch, 0 = none)")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="sharded runs: plain propose/all-gather/commit per pivot instead of the software-pipelined "
+                         "form that overlaps the exchange of pivot t+1 with the row update of pivot t")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-block shard engine + the torch.distributed collective even at N=1")
     args = ap.parse_args()
@@ -188,12 +191,14 @@ def main():
         eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank)
         t_up = time.perf_counter() - t_up
         ex = DistExchange()
-        status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=W, poll_every=args.poll_every)
+        status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=W, poll_every=args.poll_every,
+                                              lookahead=not args.no_lookahead)
         assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
         eng.profile_enable(args.event_every)
         barrier()
         t0 = time.perf_counter()
-        status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=K, poll_every=args.poll_every)
+        status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=K, poll_every=args.poll_every,
+                                              lookahead=not args.no_lookahead)
         barrier()
         elapsed = time.perf_counter() - t0
         launches, kernel_ms = eng.profile_read()
@@ -226,7 +231,7 @@ def main():
             "config": {"workload": "%s: dense random LP m=%d n=%d fp64 (A~U(0,1), b=(n/4)U(1,2), c~U(0,1), max), "
                                    "first-positive entering rule, %d pivots after %d warm-up" % (args.workload, m, n, K, W),
                        "m": m, "n": n, "seed": args.seed,
-                       "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot" % world},
+                       "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot%s" % (world, "" if args.no_lookahead else ", look-ahead pipelined")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_update", "avg_kernel_ms": avg_ms, "launches_sampled": launches,

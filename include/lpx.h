@@ -149,6 +149,21 @@ int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t nranks);
 /* The decision step of lpx_shard_commit without the row update: issued as the LAST step of a budgeted run
  * (after max_pivots commits), where it can only report LPX_UNBOUNDED or LPX_PIVOT_LIMIT.  No host sync. */
 int lpx_shard_probe(lpx_state* s, const double* d_gathered, int32_t nranks);
+/* Row-block shards, look-ahead form: the exchange and decision of pivot t+1 overlap the row update of
+ * pivot t.  The candidate of pivot t+1 only depends on the updated tableau through one column and one row,
+ * which follow from the NOT-yet-updated tableau by the rank-1 formula (bit-identical to what the update
+ * writes), so per pivot t the host issues, with slot = t & 1:
+ *     lpx_shard_peek(s, cand, (t+1)&1, 1)      main stream: candidate of pivot t+1 (pending update: pivot t)
+ *     lpx_shard_update(s, t&1)                 main stream: row update of pivot t
+ *     all-gather of cand                       comm stream (after the peek: ordered by the library)
+ *     lpx_shard_decide(s, gathered, G, (t+1)&1) comm stream: pick the winner, finish pivot t+1's decision
+ * after a prologue  lpx_shard_begin; lpx_shard_peek(s, cand, 0, 0); all-gather; lpx_shard_decide(s, .., 0).
+ * Parameter blocks, pivot rows and pivot columns are double-buffered by slot.  The library records/waits
+ * the cross-stream events; without lpx_shard_set_comm_stream everything runs on the main stream. */
+int lpx_shard_set_comm_stream(lpx_state* s, void* hip_stream);
+int lpx_shard_peek(lpx_state* s, double* d_candidate, int32_t slot, int32_t pending);
+int lpx_shard_decide(lpx_state* s, const double* d_gathered, int32_t nranks, int32_t slot);
+int lpx_shard_update(lpx_state* s, int32_t slot);
 /* Host poll of the replicated loop state: pivots done so far and LPX_RUNNING (-1, loop still live) or
  * LPX_OPTIMAL / LPX_UNBOUNDED / LPX_PIVOT_LIMIT.  Synchronises the stream. */
 #define LPX_RUNNING (-1)

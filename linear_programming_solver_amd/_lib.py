@@ -70,6 +70,10 @@ SYMBOLS = [
     ("lpx_shard_propose", C.c_int, [C.c_void_p, C.c_void_p]),
     ("lpx_shard_commit", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     ("lpx_shard_probe", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    ("lpx_shard_set_comm_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("lpx_shard_peek", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    ("lpx_shard_decide", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    ("lpx_shard_update", C.c_int, [C.c_void_p, C.c_int32]),
     ("lpx_shard_poll", C.c_int, [C.c_void_p, i64p, ip]),
     ("lpx_solve", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(SolveOptions),
                             C.POINTER(SolveResult)]),

@@ -72,6 +72,11 @@ struct lpx_state {
   Geometry g{};
   bool nontemporal = false;
   LpxCtl* h_ctl = nullptr;          // pinned mirror
+  // look-ahead pipeline of the sharded loop: parameter ring, second pivot-row buffer, second stream
+  LpxCtl* ring = nullptr;           // 2 device blocks
+  double* prow2 = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_peek = nullptr, ev_decide = nullptr;
   unsigned long long* d_sum = nullptr;
   // row-update profiling (HIP events on `stream`)
   int prof = 0;                     // 0 = off, N = bracket every N-th row-update launch with events
@@ -134,6 +139,10 @@ static void free_state(lpx_state* s) {
   (void)hipFree(s->B.perm);
   (void)hipFree(s->B.ctl);
   (void)hipFree(s->d_sum);
+  (void)hipFree(s->ring);
+  (void)hipFree(s->prow2);
+  if (s->ev_peek) (void)hipEventDestroy(s->ev_peek);
+  if (s->ev_decide) (void)hipEventDestroy(s->ev_decide);
   if (s->h_ctl) (void)hipHostFree(s->h_ctl);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
@@ -175,6 +184,8 @@ static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, 
   ALLOC(s->B.perm, (int64_t)n_cap + m_global, int32_t);
   ALLOC(s->B.ctl, 1, LpxCtl);
   ALLOC(s->d_sum, 4, unsigned long long);
+  ALLOC(s->ring, 2, LpxCtl);
+  ALLOC(s->prow2, ld, double);
 #undef ALLOC
   hipError_t e = hipHostMalloc((void**)&s->h_ctl, sizeof(LpxCtl), hipHostMallocDefault);
   if (e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, "hipHostMalloc failed"); }
@@ -182,6 +193,11 @@ static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, 
   e = hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, "hipStreamCreate failed"); }
   s->stream = s->own_stream;
+  if (hipEventCreateWithFlags(&s->ev_peek, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_decide, hipEventDisableTiming) != hipSuccess) {
+    free_state(s);
+    return fail(LPX_DEVICE_ERROR, "hipEventCreate failed");
+  }
   HIP_TRY(hipDeviceSynchronize());  // the memsets above ran on the null stream
   *out = s;
   return 0;
@@ -267,7 +283,9 @@ extern "C" int lpx_state_dims(const lpx_state* s, int32_t* m_local, int32_t* n, 
 }
 
 // ------------------------------------------------------------------------------------------------ launches
-static int launch_update_profiled(lpx_state* s) {
+static int launch_update_profiled(lpx_state* s, const double* prow = nullptr, const LpxCtl* up = nullptr) {
+  if (!prow) prow = s->B.prow;
+  if (!up) up = s->B.ctl;
   if (s->prof > 0 && (s->prof_seq++ % s->prof) == 0) {
     if (s->ev_used + 2 > s->ev.size()) {
       for (int k = 0; k < 512; k++) {
@@ -277,11 +295,11 @@ static int launch_update_profiled(lpx_state* s) {
       }
     }
     HIP_TRY(hipEventRecord(s->ev[s->ev_used], s->stream));
-    lpxk::launch_update(s->B, s->m, s->n, s->row0, s->g, s->nontemporal, s->stream);
+    lpxk::launch_update(s->B, s->m, s->n, s->row0, s->g, s->nontemporal, prow, up, s->stream);
     HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], s->stream));
     s->ev_used += 2;
   } else {
-    lpxk::launch_update(s->B, s->m, s->n, s->row0, s->g, s->nontemporal, s->stream);
+    lpxk::launch_update(s->B, s->m, s->n, s->row0, s->g, s->nontemporal, prow, up, s->stream);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -461,7 +479,7 @@ extern "C" int lpx_shard_propose(lpx_state* s, double* d_candidate) {
 extern "C" int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t nranks) {
   if (!s || !d_gathered || nranks < 1) return fail(LPX_BAD_ARGUMENT, "lpx_shard_commit: bad argument");
   HIP_TRY(hipSetDevice(s->device));
-  lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, s->stream);
+  lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, s->B.prow, s->B.ctl, -1, s->stream);
   if (int rc = launch_update_profiled(s)) return rc;
   return 0;
 }
@@ -471,16 +489,66 @@ extern "C" int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t 
 extern "C" int lpx_shard_probe(lpx_state* s, const double* d_gathered, int32_t nranks) {
   if (!s || !d_gathered || nranks < 1) return fail(LPX_BAD_ARGUMENT, "lpx_shard_probe: bad argument");
   HIP_TRY(hipSetDevice(s->device));
-  lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, s->stream);
+  lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, s->B.prow, s->B.ctl, -1, s->stream);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+// ---- look-ahead pipeline (include/lpx.h "Row-block shards, look-ahead form") -------------------------------
+extern "C" int lpx_shard_set_comm_stream(lpx_state* s, void* hip_stream) {
+  if (!s) return fail(LPX_BAD_ARGUMENT, "NULL state");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (s->comm_stream) HIP_TRY(hipStreamSynchronize(s->comm_stream));
+  s->comm_stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+static hipStream_t comm_of(lpx_state* s) { return s->comm_stream ? s->comm_stream : s->stream; }
+
+extern "C" int lpx_shard_peek(lpx_state* s, double* d_candidate, int32_t slot, int32_t pending) {
+  if (!s || !d_candidate || (slot != 0 && slot != 1)) return fail(LPX_BAD_ARGUMENT, "lpx_shard_peek: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  const int prev = slot ^ 1;
+  const double* prow_t = prev ? s->prow2 : s->B.prow;
+  lpxk::launch_peek(s->B, s->n, s->m, s->row0, prow_t, s->B.col[prev], s->B.col[slot],
+                    pending ? &s->ring[prev] : nullptr, d_candidate, s->stream);
+  HIP_TRY(hipGetLastError());
+  if (comm_of(s) != s->stream) {
+    HIP_TRY(hipEventRecord(s->ev_peek, s->stream));
+    HIP_TRY(hipStreamWaitEvent(comm_of(s), s->ev_peek, 0));
+  }
+  return 0;
+}
+
+extern "C" int lpx_shard_decide(lpx_state* s, const double* d_gathered, int32_t nranks, int32_t slot) {
+  if (!s || !d_gathered || nranks < 1 || (slot != 0 && slot != 1))
+    return fail(LPX_BAD_ARGUMENT, "lpx_shard_decide: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  double* prow = slot ? s->prow2 : s->B.prow;
+  // parity = slot^1 makes k_update(slot) read col[slot], the column k_peek produced for this pivot
+  lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, prow, &s->ring[slot], slot ^ 1, comm_of(s));
+  HIP_TRY(hipGetLastError());
+  if (comm_of(s) != s->stream) {
+    HIP_TRY(hipEventRecord(s->ev_decide, comm_of(s)));
+    HIP_TRY(hipStreamWaitEvent(s->stream, s->ev_decide, 0));
+  }
+  return 0;
+}
+
+extern "C" int lpx_shard_update(lpx_state* s, int32_t slot) {
+  if (!s || (slot != 0 && slot != 1)) return fail(LPX_BAD_ARGUMENT, "lpx_shard_update: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  return launch_update_profiled(s, slot ? s->prow2 : s->B.prow, &s->ring[slot]);
 }
 
 // Starts (or restarts) a sharded loop: resets the replicated loop state and seeds column/partials.
 extern "C" int lpx_shard_begin(lpx_state* s, int64_t max_pivots, int32_t track_slot) {
   if (!s) return fail(LPX_BAD_ARGUMENT, "lpx_shard_begin: NULL state");
   HIP_TRY(hipSetDevice(s->device));
+  if (s->comm_stream) HIP_TRY(hipStreamSynchronize(s->comm_stream));
   if (int rc = set_running(s, max_pivots, track_slot)) return rc;
+  HIP_TRY(hipMemsetAsync(s->ring, 0, 2 * sizeof(LpxCtl), s->stream));
   lpxk::launch_entering(s->B, s->n, s->stream);
   lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, -1, s->stream);
   HIP_TRY(hipGetLastError());
@@ -490,6 +558,7 @@ extern "C" int lpx_shard_begin(lpx_state* s, int64_t max_pivots, int32_t track_s
 extern "C" int lpx_shard_poll(lpx_state* s, int64_t* pivots_done, int32_t* status) {
   if (!s) return fail(LPX_BAD_ARGUMENT, "lpx_shard_poll: NULL state");
   HIP_TRY(hipSetDevice(s->device));
+  if (s->comm_stream) HIP_TRY(hipStreamSynchronize(s->comm_stream));
   if (int rc = sync_ctl_to_host(s)) return rc;
   if (pivots_done) *pivots_done = s->h_ctl->pivots;
   if (status) *status = s->h_ctl->status;  // LPX_RUNNING (-1) while the loop is live

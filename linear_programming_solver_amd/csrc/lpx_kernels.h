@@ -64,12 +64,18 @@ void launch_reduce_partials(const Buffers& B, const Geometry& g, hipStream_t s);
 // forced_l >= 0 (global row): pivot(forced_e, forced_l) of the step API, no ratio test
 void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& g, int forced_e, int forced_l,
                          hipStream_t s);
+// prow / up: the normalised pivot row and the parameter block of the pivot to apply (B.prow / B.ctl in the
+// two-launch loop, one ring slot in the look-ahead pipeline)
 void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometry& g, bool nontemporal,
-                   hipStream_t s);
+                   const double* prow, const LpxCtl* up, hipStream_t s);
 // shards
 void launch_propose(const Buffers& B, int n, int row0, int m_local, const Geometry& g, double* d_candidate,
                     hipStream_t s);
-void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, hipStream_t s);
+void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, double* prow,
+                   LpxCtl* up, int up_parity, hipStream_t s);
+// look-ahead: candidate of the NEXT pivot computed from the tableau BEFORE the pending update `pend`
+void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* prow_t, const double* col_t,
+                 double* col_next, const LpxCtl* pend, double* d_candidate, hipStream_t s);
 // phase 1 / restore helpers
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
 void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);

@@ -144,13 +144,21 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const RatioRow* __restr
 // workgroup that draws the last ticket finalises the replicated loop state.  Nobody spins, so no residency
 // assumption is needed.  ctl fields are only ever written by that last workgroup (or by workgroup 0 on
 // the early exits that all workgroups take alike), after every workgroup has read what it needs.
+//
+// `up` is the parameter block the row update of THIS pivot will read: ctl itself in the two-launch loop,
+// one slot of a ring in the look-ahead pipeline (where the decision for pivot t+1 is taken while the update
+// of pivot t is still streaming, see k_peek); up_parity >= 0 then fixes which col buffer that update reads.
 __device__ __forceinline__ void finish_pivot(const double* __restrict__ raw_row, double raw_b, int e,
                                              int l_global, double ratio, double* __restrict__ prow,
                                              double* __restrict__ c, int n, int64_t ld, int32_t* perm,
-                                             LpxCtl* ctl, int* sh_int) {
+                                             LpxCtl* ctl, LpxCtl* up, int up_parity, int* sh_int) {
   const double p = raw_row[e];
   if (p == 0.0) {  // ArithmeticException in the reference (BigDecimal.divide by zero), :139
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ctl->status = 8 /* LPX_DIVIDE_BY_ZERO */; ctl->do_update = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ctl->status = 8 /* LPX_DIVIDE_BY_ZERO */;
+      ctl->do_update = 0;
+      up->do_update = 0;
+    }
     return;
   }
   const double pc = c[e];  // c[e] itself is rewritten only by the finalising workgroup
@@ -200,6 +208,15 @@ __device__ __forceinline__ void finish_pivot(const double* __restrict__ raw_row,
       ctl->parity ^= 1;  // k_update reads col[parity^1] (column e_cur) and fills col[parity] (column e_next)
       ctl->pivots += 1;
       ctl->do_update = 1;
+      if (up != ctl) {  // look-ahead ring slot: only what k_update / k_peek read
+        up->p = p;
+        up->bl = bl;
+        up->e_cur = e;
+        up->l = l_global;
+        up->e_next = -1;           // no by-products: the next column / ratios come from k_peek
+        up->parity = up_parity;
+        up->do_update = 1;
+      }
       atomicExch(&ctl->e_min, INT_MAX);
       atomicExch(&ctl->ticket, 0);
     }
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(1024) void k_select_pivot(const double* __restrict_
     }
   }
   (void)m_global;
-  finish_pivot(A + (int64_t)l * ld, b[l], e, l, ratio, prow, c, n, ld, perm, ctl, sh_int);
+  finish_pivot(A + (int64_t)l * ld, b[l], e, l, ratio, prow, c, n, ld, perm, ctl, ctl, -1, sh_int);
 }
 
 // ------------------------------------------------------------------------------------------------ k_update
@@ -434,11 +451,11 @@ __global__ __launch_bounds__(1024) void k_propose(const double* __restrict__ A, 
 // k_commit: identical on every rank — pick the winner (min ratio, lowest global row) and finish the pivot.
 __global__ __launch_bounds__(1024) void k_commit(const double* __restrict__ gathered, int nranks, int n,
                                                  int64_t ld, int m_global, double* c, double* prow,
-                                                 int32_t* perm, LpxCtl* ctl) {
+                                                 int32_t* perm, LpxCtl* ctl, LpxCtl* up, int up_parity) {
   __shared__ int sh_int[16];
   const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
   if (ctl->status != kRunning) {
-    if (writer) ctl->do_update = 0;
+    if (writer) { ctl->do_update = 0; up->do_update = 0; }
     return;
   }
   const int64_t pivots = ctl->pivots, max_pivots = ctl->max_pivots;
@@ -455,16 +472,124 @@ __global__ __launch_bounds__(1024) void k_commit(const double* __restrict__ gath
     }
   }
   if (win < 0 || !(best.ratio < kInf)) {
-    if (writer) { ctl->status = 1 /* LPX_UNBOUNDED */; ctl->do_update = 0; ctl->l = -1; ctl->ratio = best.ratio; }
+    if (writer) {
+      ctl->status = 1 /* LPX_UNBOUNDED */; ctl->do_update = 0; ctl->l = -1; ctl->ratio = best.ratio;
+      up->do_update = 0;
+    }
     return;
   }
   if (max_pivots >= 0 && pivots >= max_pivots) {
-    if (writer) { ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; }
+    if (writer) { ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; up->do_update = 0; }
     return;
   }
   const double* h = gathered + win * rec;
   (void)m_global;
-  finish_pivot(h + 8, h[4], e, best.row, best.ratio, prow, c, n, ld, perm, ctl, sh_int);
+  finish_pivot(h + 8, h[4], e, best.row, best.ratio, prow, c, n, ld, perm, ctl, up, up_parity, sh_int);
+}
+
+// ------------------------------------------------------------------------------------------------ look-ahead
+// The ratio test of pivot t+1 and the winning row itself depend on the tableau AFTER pivot t only through
+// one column and one row, and both follow from the tableau BEFORE pivot t by the rank-1 formula:
+//     A'[i][e'] = A[i][e'] - col[i]*prow[e']   (i != l; = prow[e'] for i == l; = -(col[i]/p) for e' == e)
+//     b'[i]     = b[i] - col[i]*b_l            (i != l; = b_l for i == l)
+// (the very operations k_update performs, so the values are bit-identical).  k_peek therefore produces the
+// shard's candidate for pivot t+1 in O(m + n) work BEFORE k_update(t) starts streaming, and the exchange
+// (all-gather) and decision (k_commit) of pivot t+1 overlap the row update of pivot t on a second stream.
+// `pend` = parameter block of the pivot whose update has not been applied yet (NULL / do_update == 0: none).
+__global__ __launch_bounds__(256) void k_peek(const double* __restrict__ A, int64_t ld,
+                                              const double* __restrict__ b, int m_local, int row0,
+                                              const double* __restrict__ prow_t, const double* __restrict__ col_t,
+                                              double* __restrict__ col_next, RatioRow* __restrict__ partial,
+                                              const LpxCtl* __restrict__ ctl, const LpxCtl* __restrict__ pend) {
+  __shared__ RatioRow sh[4];
+  if (ctl->status != kRunning) return;
+  const int en = ctl->e_next;
+  if (en < 0) return;
+  const bool pending = pend != nullptr && pend->do_update != 0;
+  int e_t = -1, l_t = -1;
+  double p = 1.0, bl = 0.0, pe = 0.0;
+  if (pending) {
+    e_t = pend->e_cur;
+    l_t = pend->l - row0;
+    p = pend->p;
+    bl = pend->bl;
+    pe = prow_t[en];
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  RatioRow best = rr_none();
+  if (i < m_local) {
+    const double a_old = A[(int64_t)i * ld + en];
+    double a, bn;
+    if (!pending) {
+      a = a_old;
+      bn = b[i];
+    } else {
+      const double ce = col_t[i];
+      if (i == l_t) {
+        a = pe;
+        bn = bl;
+      } else {
+        a = (en == e_t) ? -__ddiv_rn(ce, p) : __dsub_rn(a_old, __dmul_rn(ce, pe));
+        bn = __dsub_rn(b[i], __dmul_rn(ce, bl));
+      }
+    }
+    col_next[i] = a;
+    const double r = ratio_of(a, bn);
+    if (r < kInf) best = RatioRow{r, row0 + i, 0};
+  }
+  best = rr_block_min(best, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = best;
+}
+
+// Folds k_peek's partials into the shard's candidate record and computes the candidate ROW as it will be
+// after the pending update (same record layout as k_propose).
+__global__ __launch_bounds__(1024) void k_peek_pack(const double* __restrict__ A, int64_t ld, int n, int row0,
+                                                    const double* __restrict__ b,
+                                                    const double* __restrict__ prow_t,
+                                                    const double* __restrict__ col_t,
+                                                    const RatioRow* __restrict__ partial, int nparts,
+                                                    const LpxCtl* __restrict__ ctl,
+                                                    const LpxCtl* __restrict__ pend, double* __restrict__ cand) {
+  __shared__ RatioRow sh_rr[16];
+  const int st = ctl->status;
+  RatioRow best = rr_none();
+  if (st == kRunning && ctl->e_next >= 0) {
+    for (int k = threadIdx.x; k < nparts; k += blockDim.x) best = rr_min(best, partial[k]);
+    best = rr_block_min(best, sh_rr);
+  }
+  const bool have = best.ratio < kInf;
+  const int lr = have ? best.row - row0 : -1;
+  const bool pending = pend != nullptr && pend->do_update != 0;
+  int e_t = -1, l_t = -1;
+  double p = 1.0, bl = 0.0, ce = 0.0;
+  if (pending && have) {
+    e_t = pend->e_cur;
+    l_t = pend->l - row0;
+    p = pend->p;
+    bl = pend->bl;
+    ce = col_t[lr];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    cand[0] = (st == kRunning) ? 0.0 : (double)(st + 1);
+    cand[1] = (double)ctl->e_next;
+    cand[2] = best.ratio;
+    cand[3] = have ? (double)best.row : -1.0;
+    double bn = 0.0;
+    if (have) bn = !pending ? b[lr] : (lr == l_t ? bl : __dsub_rn(b[lr], __dmul_rn(ce, bl)));
+    cand[4] = bn;
+    cand[5] = cand[6] = cand[7] = 0.0;
+  }
+  if (have) {
+    const double* row = A + (int64_t)lr * ld;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+      double x = row[j];
+      if (pending) {
+        if (lr == l_t) x = prow_t[j];
+        else x = (j == e_t) ? -__ddiv_rn(ce, p) : __dsub_rn(x, __dmul_rn(ce, prow_t[j]));
+      }
+      cand[8 + j] = x;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ phase 1 helpers
@@ -601,18 +726,20 @@ void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& 
 }
 
 template <int U, bool NT>
-static void launch_update_t(const Buffers& B, int m_local, int row0, const Geometry& g, hipStream_t s) {
+static void launch_update_t(const Buffers& B, int m_local, int row0, const Geometry& g, const double* prow,
+                            const LpxCtl* up, hipStream_t s) {
   hipLaunchKernelGGL((k_update<U, NT>), dim3(g.nstrips * g.ntiles), dim3(256), 0, s, B.A, B.ld, m_local, row0,
-                     B.b, B.prow, B.col[0], B.col[1], B.partial, B.ctl, g.rows_per_tile, g.nstrips);
+                     B.b, prow, B.col[0], B.col[1], B.partial, up, g.rows_per_tile, g.nstrips);
 }
 
-void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometry& g, bool nt, hipStream_t s) {
+void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometry& g, bool nt, const double* prow,
+                   const LpxCtl* up, hipStream_t s) {
   (void)n;
   if (g.ntiles <= 0 || g.nstrips <= 0) return;
   switch (g.U) {
-    case 1: nt ? launch_update_t<1, true>(B, m_local, row0, g, s) : launch_update_t<1, false>(B, m_local, row0, g, s); break;
-    case 2: nt ? launch_update_t<2, true>(B, m_local, row0, g, s) : launch_update_t<2, false>(B, m_local, row0, g, s); break;
-    default: nt ? launch_update_t<4, true>(B, m_local, row0, g, s) : launch_update_t<4, false>(B, m_local, row0, g, s); break;
+    case 1: nt ? launch_update_t<1, true>(B, m_local, row0, g, prow, up, s) : launch_update_t<1, false>(B, m_local, row0, g, prow, up, s); break;
+    case 2: nt ? launch_update_t<2, true>(B, m_local, row0, g, prow, up, s) : launch_update_t<2, false>(B, m_local, row0, g, prow, up, s); break;
+    default: nt ? launch_update_t<4, true>(B, m_local, row0, g, prow, up, s) : launch_update_t<4, false>(B, m_local, row0, g, prow, up, s); break;
   }
 }
 
@@ -622,9 +749,19 @@ void launch_propose(const Buffers& B, int n, int row0, int m_local, const Geomet
                      g.ntiles, B.ctl, d_candidate);
 }
 
-void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, hipStream_t s) {
-  hipLaunchKernelGGL(k_commit, dim3(finish_blocks(B.ld)), dim3(1024), 0, s, d_gathered, nranks, n, B.ld, m_global, B.c, B.prow,
-                     B.perm, B.ctl);
+void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, double* prow,
+                   LpxCtl* up, int up_parity, hipStream_t s) {
+  hipLaunchKernelGGL(k_commit, dim3(finish_blocks(B.ld)), dim3(1024), 0, s, d_gathered, nranks, n, B.ld, m_global, B.c,
+                     prow, B.perm, B.ctl, up, up_parity);
+}
+
+void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* prow_t, const double* col_t,
+                 double* col_next, const LpxCtl* pend, double* d_candidate, hipStream_t s) {
+  const int nblk = std::max(1, (m_local + 255) / 256);
+  hipLaunchKernelGGL(k_peek, dim3(nblk), dim3(256), 0, s, B.A, B.ld, B.b, m_local, row0, prow_t, col_t, col_next,
+                     B.partial, B.ctl, pend);
+  hipLaunchKernelGGL(k_peek_pack, dim3(finish_blocks(B.ld)), dim3(1024), 0, s, B.A, B.ld, n, row0, B.b, prow_t, col_t,
+                     B.partial, nblk, B.ctl, pend, d_candidate);
 }
 
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {

@@ -34,7 +34,8 @@ class HipShardEngine:
     tensors so that torch.distributed (backend "nccl" = RCCL) can move them; kernels are issued on torch's
     current stream."""
 
-    def __init__(self, A_local, b_local, c, row0, m_global, nranks, device=0, perm=None, v=0.0, stream=None):
+    def __init__(self, A_local, b_local, c, row0, m_global, nranks, device=0, perm=None, v=0.0, stream=None,
+                 comm_stream=None):
         import torch
         self.torch = torch
         L = _lib.lib()
@@ -66,6 +67,11 @@ class HipShardEngine:
         rc = self._L.lpx_state_set_stream(self._h, C.c_void_p(self.stream.cuda_stream))
         if rc:
             raise_for_status(rc)
+        # second stream of the look-ahead pipeline: all-gather + decision of pivot t+1 beside the update of t
+        self.comm_stream = comm_stream if comm_stream is not None else torch.cuda.Stream(device=dev)
+        rc = self._L.lpx_shard_set_comm_stream(self._h, C.c_void_p(self.comm_stream.cuda_stream))
+        if rc:
+            raise_for_status(rc)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -91,6 +97,22 @@ class HipShardEngine:
     def commit(self, probe_only=False):
         fn = self._L.lpx_shard_probe if probe_only else self._L.lpx_shard_commit
         rc = fn(self._h, C.c_void_p(self.gathered.data_ptr()), self.nranks)
+        if rc:
+            raise_for_status(rc)
+
+    # ---- look-ahead form
+    def peek(self, slot, pending):
+        rc = self._L.lpx_shard_peek(self._h, C.c_void_p(self.cand.data_ptr()), int(slot), 1 if pending else 0)
+        if rc:
+            raise_for_status(rc)
+
+    def decide(self, slot):
+        rc = self._L.lpx_shard_decide(self._h, C.c_void_p(self.gathered.data_ptr()), self.nranks, int(slot))
+        if rc:
+            raise_for_status(rc)
+
+    def update(self, slot):
+        rc = self._L.lpx_shard_update(self._h, int(slot))
         if rc:
             raise_for_status(rc)
 
@@ -140,9 +162,9 @@ class DistExchange:
         self.dist = dist
         self.group = group
 
-    def all_gather(self, engines):
+    def all_gather(self, engines, comm=False):
         (eng,) = engines
-        stream = getattr(eng, "stream", None)
+        stream = getattr(eng, "comm_stream" if comm else "stream", None)
         if stream is None:   # CPU engine (gloo)
             self.dist.all_gather_into_tensor(eng.gathered, eng.cand, group=self.group)
         else:
@@ -153,24 +175,63 @@ class DistExchange:
 class LocalExchange:
     """All shards live in this process (rank-free rehearsal of the protocol on one GPU / in unit tests)."""
 
-    def all_gather(self, engines):
+    def all_gather(self, engines, comm=False):
         torch = engines[0].torch
-        stream = getattr(engines[0], "stream", None)
+        attr = "comm_stream" if comm else "stream"
+        stream = getattr(engines[0], attr, None)
         if stream is None:
             cat = torch.cat([e.cand for e in engines])
             for e in engines:
                 e.gathered.copy_(cat)
             return
-        assert all(e.stream is stream for e in engines), "local rehearsal: all shards must share one stream"
+        assert all(getattr(e, attr) is stream for e in engines), "local rehearsal: all shards must share streams"
         with torch.cuda.stream(stream):
             cat = torch.cat([e.cand for e in engines])
             for e in engines:
                 e.gathered.copy_(cat)
 
 
-def sharded_simplex_loop(engines, exchange, max_pivots=-1, track_slot=-1, poll_every=16):
+def sharded_simplex_loop_lookahead(engines, exchange, max_pivots=-1, track_slot=-1, poll_every=16):
+    """Same loop, software-pipelined: the candidate of pivot t+1 is computed (peek) from the tableau BEFORE
+    the update of pivot t, so the all-gather and the decision of pivot t+1 run on the comm stream while the
+    row update of pivot t streams on the main stream.  Results are bit-identical to the plain form.
+    Returns (status, pivots, updates_issued)."""
+    for e in engines:
+        e.begin(max_pivots, track_slot)
+    for e in engines:
+        e.peek(0, False)
+    exchange.all_gather(engines, comm=True)
+    for e in engines:
+        e.decide(0)
+    issued = 0   # row updates issued == decisions issued - 1
+    while True:
+        burst = poll_every
+        if max_pivots >= 0:
+            burst = max(0, min(burst, max_pivots - issued))   # decision number max_pivots is the budget probe
+        for k in range(burst):
+            t = issued + k
+            for e in engines:
+                e.peek((t + 1) & 1, True)
+            for e in engines:
+                e.update(t & 1)
+            exchange.all_gather(engines, comm=True)
+            for e in engines:
+                e.decide((t + 1) & 1)
+        issued += burst
+        polled = [e.poll() for e in engines]
+        pivots, status = polled[0]
+        assert all(p == polled[0] for p in polled), "replicated loop state diverged: %r" % (polled,)
+        if status != RUNNING:
+            return status, pivots, issued
+        if burst == 0:
+            raise RuntimeError("pivot budget exhausted but loop still running")
+
+
+def sharded_simplex_loop(engines, exchange, max_pivots=-1, track_slot=-1, poll_every=16, lookahead=False):
     """LPSolver.simplex's loop (LPSolver.java:101-107) over row-block shards.  `engines`: the shard engines
     living in this process (one per rank in production).  Returns (status, pivots, iterations_issued)."""
+    if lookahead:
+        return sharded_simplex_loop_lookahead(engines, exchange, max_pivots, track_slot, poll_every)
     for e in engines:
         e.begin(max_pivots, track_slot)
     issued = 0

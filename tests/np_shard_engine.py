@@ -77,13 +77,10 @@ class NumpyShardEngine:
         prow[e] = 1.0 / p
         bl = raw_b / p
         ce = self.A[:, e].copy()
-        self.A = self.A - ce[:, None] * prow[None, :]
-        self.A[:, e] = -(ce / p)
-        self.b = self.b - ce * bl
         li = l - self.row0
-        if 0 <= li < self.m_local:
-            self.A[li] = prow
-            self.b[li] = bl
+        self._pending = (ce, prow, e, p, bl, li)
+        if not getattr(self, "_defer", False):
+            self._apply_pending()
         pc = self.c[e]
         self.v = self.v + bl * pc
         cn = self.c - pc * prow
@@ -100,8 +97,37 @@ class NumpyShardEngine:
         if self.e_next < 0:
             self.status = OPTIMAL
 
+    # ---- look-ahead form.  A sequential engine has nothing to overlap: the decision is stored, the "pending"
+    # update is applied when the next peek (or a read) needs the tableau, which is observably identical.
+    _pending = None
+    comm_stream = None
+
+    def decide(self, slot):
+        self._defer = True
+        self.commit()
+        self._defer = False
+
+    def update(self, slot):
+        pass
+
+    def peek(self, slot, pending):
+        self._apply_pending()
+        self.propose()
+
+    def _apply_pending(self):
+        if self._pending is not None:
+            ce, prow, e, p, bl, li = self._pending
+            self._pending = None
+            self.A = self.A - ce[:, None] * prow[None, :]
+            self.A[:, e] = -(ce / p)
+            self.b = self.b - ce * bl
+            if 0 <= li < self.m_local:
+                self.A[li] = prow
+                self.b[li] = bl
+
     def poll(self):
         return self.pivots, self.status
 
     def read(self, want_A=True):
+        self._apply_pending()
         return (self.A if want_A else None), self.b, self.c, self.v, self.perm

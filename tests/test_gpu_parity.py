@@ -322,21 +322,24 @@ def test_cfg2_first_pivots_follow_the_decimal_reference(lps, oracle):
 
 
 # ------------------------------------------------------------------------------------ row-block shards
+@pytest.mark.parametrize("lookahead", [False, True])
 @pytest.mark.parametrize("nshards,shape,budget", [(2, (64, 100), -1), (4, (130, 513), 25), (8, (257, 2100), 12),
-                                                  (3, (10, 40), -1)])
-def test_shard_kernels_on_one_gpu_match_oracle(lps, oracle, nshards, shape, budget):
+                                                  (3, (10, 40), -1), (1, (300, 700), -1), (5, (1000, 260), 40)])
+def test_shard_kernels_on_one_gpu_match_oracle(lps, oracle, nshards, shape, budget, lookahead):
     """k_propose / k_commit / k_update on row-block shards, all shards living on this one GPU and exchanging
     through LocalExchange (the multi-GPU protocol minus RCCL): bit-exact against the unsharded oracle."""
     import torch
     from linear_programming_solver_amd.sharded import HipShardEngine, LocalExchange, row_block, sharded_simplex_loop
     m, n = shape
     A, b, c = dense_lp(m, n, seed=m + n)
-    stream = torch.cuda.Stream()
+    stream, comm = torch.cuda.Stream(), torch.cuda.Stream()
     engines = []
     for r in range(nshards):
         r0, r1 = row_block(m, nshards, r)
-        engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, nshards, device=0, stream=stream))
-    status, pivots, _ = sharded_simplex_loop(engines, LocalExchange(), max_pivots=budget, poll_every=7)
+        engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, nshards, device=0, stream=stream,
+                                      comm_stream=comm))
+    status, pivots, _ = sharded_simplex_loop(engines, LocalExchange(), max_pivots=budget, poll_every=7,
+                                             lookahead=lookahead)
     ref = oracle.State(A, b, c, kind=oracle.FP64)
     want = ref.simplex_loop(max_pivots=budget)
     assert (status, pivots) == (want["status"], want["pivots"])
@@ -495,13 +498,14 @@ def test_cfg4_size_properties_and_sharding_invariance(lps):
     single = (st.checksum(), gb.copy(), gc.copy(), gv, gperm.copy())
     st.close()
     nsh = 8
-    stream = torch.cuda.Stream()
+    stream, comm = torch.cuda.Stream(), torch.cuda.Stream()
     engines = []
     for r in range(nsh):
         r0, r1 = row_block(m, nsh, r)
-        engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, nsh, device=0, stream=stream))
-    for _ in range(3):
-        status, pivots, _ = sharded_simplex_loop(engines, LocalExchange(), max_pivots=5, poll_every=4)
+        engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, nsh, device=0, stream=stream, comm_stream=comm))
+    for rep in range(3):
+        status, pivots, _ = sharded_simplex_loop(engines, LocalExchange(), max_pivots=5, poll_every=4,
+                                                 lookahead=(rep != 1))
         assert (status, pivots) == (9, 5)
     sums = [e.checksum() for e in engines]
     mask = (1 << 64) - 1
