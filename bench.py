@@ -156,8 +156,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        pg_opts = None
+        try:  # RCCL's kernels run beside the streaming row update (look-ahead pipeline): high-priority stream
+            pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:
+            pg_opts = None
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+                                device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
 
     m, n = WORKLOADS[args.workload]
     r0, r1 = row_block(m, world, rank)

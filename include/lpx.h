@@ -86,6 +86,12 @@ void lpx_state_destroy(lpx_state* s);
 /* Issue all further device work of this handle on `hip_stream` (a hipStream_t; NULL = the handle's own). */
 int lpx_state_set_stream(lpx_state* s, void* hip_stream);
 
+/* Replace the handle's own stream by one whose CU mask leaves `reserve_xcds` (0..4) whole XCDs (32 CUs each)
+ * to OTHER streams, and make it the handle's stream.  The row update is HBM-bound and keeps its full rate on 7
+ * XCDs; the reserved XCD guarantees that a collective or a decision kernel issued on another stream runs
+ * beside it (look-ahead pipeline).  *stream_out receives the hipStream_t (wrap it, e.g. torch ExternalStream). */
+int lpx_state_use_masked_stream(lpx_state* s, int32_t reserve_xcds, void** stream_out);
+
 /* int getEntering()                                                    LPState.java:274-285
  * *entering = min{ j in [0,n) : c[j] > 1e-9 } or -1. */
 int lpx_get_entering(lpx_state* s, int32_t* entering);

@@ -57,6 +57,7 @@ SYMBOLS = [
                                                C.POINTER(C.c_void_p)]),
     ("lpx_state_destroy", None, [C.c_void_p]),
     ("lpx_state_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("lpx_state_use_masked_stream", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     ("lpx_get_entering", C.c_int, [C.c_void_p, ip]),
     ("lpx_get_leaving", C.c_int, [C.c_void_p, C.c_int32, ip, dp]),
     ("lpx_pivot", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

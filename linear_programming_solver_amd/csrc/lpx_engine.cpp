@@ -494,6 +494,33 @@ extern "C" int lpx_shard_probe(lpx_state* s, const double* d_gathered, int32_t n
   return 0;
 }
 
+// Measured on MI355X (cfg3, profiles/r01_cu_mask.log): with the CU-mask bits of ONE whole XCD cleared (bit i
+// belongs to XCD i % 8) the HBM-bound row update keeps its full 6.3 TB/s on the remaining 7 XCDs, while
+// clearing a few CUs of one XCD slows it down (the round-robin workgroup dealer then waits for that XCD).
+extern "C" int lpx_state_use_masked_stream(lpx_state* s, int32_t reserve_xcds, void** stream_out) {
+  if (!s || reserve_xcds < 0 || reserve_xcds > 4) return fail(LPX_BAD_ARGUMENT, "lpx_state_use_masked_stream: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  hipStream_t ns = nullptr;
+  if (reserve_xcds == 0) {
+    HIP_TRY(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+  } else {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
+    if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
+    for (int cu = 0; cu < ncu; cu++)
+      if ((cu % 8) >= 8 - reserve_xcds) mask[cu / 32] &= ~(1u << (cu % 32));
+    HIP_TRY(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
+  }
+  if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
+  s->own_stream = ns;
+  s->stream = ns;
+  if (stream_out) *stream_out = (void*)ns;
+  return 0;
+}
+
 // ---- look-ahead pipeline (include/lpx.h "Row-block shards, look-ahead form") -------------------------------
 extern "C" int lpx_shard_set_comm_stream(lpx_state* s, void* hip_stream) {
   if (!s) return fail(LPX_BAD_ARGUMENT, "NULL state");

@@ -749,9 +749,14 @@ void launch_propose(const Buffers& B, int n, int row0, int m_local, const Geomet
                      g.ntiles, B.ctl, d_candidate);
 }
 
+// Kernels that must slip in BESIDE a running row update (look-ahead pipeline) use 256-thread workgroups: a
+// 1024-thread workgroup needs 16 free wave slots on one CU at once, which never happens while k_update's
+// 256-thread workgroups keep refilling every CU (measured: such a kernel only completes when k_update drains).
+static int small_blocks(int64_t ld) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, (ld + 255) / 256)); }
+
 void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, double* prow,
                    LpxCtl* up, int up_parity, hipStream_t s) {
-  hipLaunchKernelGGL(k_commit, dim3(finish_blocks(B.ld)), dim3(1024), 0, s, d_gathered, nranks, n, B.ld, m_global, B.c,
+  hipLaunchKernelGGL(k_commit, dim3(small_blocks(B.ld)), dim3(256), 0, s, d_gathered, nranks, n, B.ld, m_global, B.c,
                      prow, B.perm, B.ctl, up, up_parity);
 }
 
@@ -760,7 +765,7 @@ void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* p
   const int nblk = std::max(1, (m_local + 255) / 256);
   hipLaunchKernelGGL(k_peek, dim3(nblk), dim3(256), 0, s, B.A, B.ld, B.b, m_local, row0, prow_t, col_t, col_next,
                      B.partial, B.ctl, pend);
-  hipLaunchKernelGGL(k_peek_pack, dim3(finish_blocks(B.ld)), dim3(1024), 0, s, B.A, B.ld, n, row0, B.b, prow_t, col_t,
+  hipLaunchKernelGGL(k_peek_pack, dim3(small_blocks(B.ld)), dim3(256), 0, s, B.A, B.ld, n, row0, B.b, prow_t, col_t,
                      B.partial, nblk, B.ctl, pend, d_candidate);
 }
 

@@ -35,7 +35,7 @@ class HipShardEngine:
     current stream."""
 
     def __init__(self, A_local, b_local, c, row0, m_global, nranks, device=0, perm=None, v=0.0, stream=None,
-                 comm_stream=None):
+                 comm_stream=None, reserve_xcds=1):
         import torch
         self.torch = torch
         L = _lib.lib()
@@ -63,12 +63,23 @@ class HipShardEngine:
         torch.cuda.synchronize(dev)
         # Kernels and the collective must be ordered on ONE explicit stream: torch's default stream is the
         # NULL stream, which a non-blocking HIP stream does not synchronise with.
-        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
-        rc = self._L.lpx_state_set_stream(self._h, C.c_void_p(self.stream.cuda_stream))
+        if stream is not None:
+            self.stream = stream
+            rc = self._L.lpx_state_set_stream(self._h, C.c_void_p(self.stream.cuda_stream))
+        else:
+            # the library's own stream with one XCD (32 of 256 CUs) masked out: the HBM-bound row update keeps its
+            # rate on 7 XCDs and the collective / decision kernels of the comm stream always find free CUs
+            raw = C.c_void_p()
+            rc = self._L.lpx_state_use_masked_stream(self._h, int(reserve_xcds), C.byref(raw))
+            if not rc:
+                self.stream = torch.cuda.ExternalStream(raw.value, device=dev)
         if rc:
             raise_for_status(rc)
         # second stream of the look-ahead pipeline: all-gather + decision of pivot t+1 beside the update of t
-        self.comm_stream = comm_stream if comm_stream is not None else torch.cuda.Stream(device=dev)
+        # High priority: a decision kernel of <=16 workgroups must be dispatched between the 10^5 workgroups of
+        # the streaming row update instead of queueing behind them (measured: without it the "overlapped"
+        # k_commit only completes when k_update drains).
+        self.comm_stream = comm_stream if comm_stream is not None else torch.cuda.Stream(device=dev, priority=-1)
         rc = self._L.lpx_shard_set_comm_stream(self._h, C.c_void_p(self.comm_stream.cuda_stream))
         if rc:
             raise_for_status(rc)
