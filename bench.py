@@ -70,6 +70,33 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("LPX_BENCH_CPU_THREADS", "16"))))
 
 
+def java_baseline(m_full, n, budget_s):
+    """if a JDK exists on this box, time bench_java/PivotBench.java (BigDecimal, 4 threads,
+    the reference's pivotConcurrently structure) at cfg2 size and scale by element count.  The build image has
+    no JDK, so this normally reports unavailable."""
+    import shutil
+    import subprocess
+    import tempfile
+    javac, java = shutil.which("javac"), shutil.which("java")
+    if not javac or not java:
+        return {"available": False, "reason": "no JDK on this box (javac/java not on PATH)"}
+    try:
+        out = tempfile.mkdtemp(prefix="lpx_java_")
+        subprocess.check_call([javac, "-d", out, os.path.join(ROOT, "bench_java", "PivotBench.java")], timeout=120)
+        ms, ns, piv = 1024, 2048, 10
+        r = subprocess.run([java, "-Xmx8g", "-cp", out, "PivotBench", str(ms), str(ns), str(piv), "1"],
+                           capture_output=True, text=True, timeout=max(60, 6 * budget_s))
+        tok = [ln for ln in r.stdout.splitlines() if ln.startswith("JAVA_PIVOTS_PER_SEC")][-1].split()
+        pps, done, secs = float(tok[1]), int(tok[2]), float(tok[3])
+        scale = (float(m_full) * n) / (ms * ns)
+        ver = subprocess.run([java, "-version"], capture_output=True, text=True).stderr.splitlines()[0]
+        return {"available": True, "value": pps / scale, "unit": "pivots/s", "cores": 4, "kind": "reference-restatement",
+                "sample": "%d BigDecimal pivots (MathContext(15,HALF_UP), 4 threads, pivotConcurrently's partitions) at "
+                          "%dx%d in %.2f s, scaled x%.3g by element count; %s" % (done, ms, ns, secs, scale, ver)}
+    except Exception as ex:  # never let the optional baseline break the bench line
+        return {"available": False, "reason": "java harness failed: %r" % (ex,)}
+
+
 def cpu_baselines(A, b, c, m_full, budget_s):
     """Times the CPU oracle on the first rows of the tableau (bounded sample) and scales to the full height:
     one pivot costs exactly m*n element updates, so time scales linearly in the number of rows."""
@@ -250,6 +277,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rows_s = min(m, 8192)
             line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))
+            line["cpu_baseline_java"] = java_baseline(m, n, args.cpu_budget_s)
             line["gpu_over_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
             line["gpu_over_cpu_baseline_fp64"] = line["value"] / line["cpu_baseline_fp64"]["value"]
         os.write(json_fd, (json.dumps(line) + "\n").encode())
