@@ -92,6 +92,12 @@ int lpx_state_set_stream(lpx_state* s, void* hip_stream);
  * beside it (look-ahead pipeline).  *stream_out receives the hipStream_t (wrap it, e.g. torch ExternalStream). */
 int lpx_state_use_masked_stream(lpx_state* s, int32_t reserve_xcds, void** stream_out);
 
+/* Entering rule of this handle.  0 (default) = the reference's rule: first slot with c[j] > 1e-9
+ * (LPState.java:274-285).  1 = Dantzig: largest c[j], lowest slot on ties — an OPT-IN extension of this
+ * library: it reaches the same optimum in ~10x fewer pivots on dense LPs but deliberately leaves
+ * the reference's pivot sequence, so basis/trace parity with the reference no longer applies. */
+int lpx_state_set_pricing(lpx_state* s, int32_t pricing);
+
 /* int getEntering()                                                    LPState.java:274-285
  * *entering = min{ j in [0,n) : c[j] > 1e-9 } or -1. */
 int lpx_get_entering(lpx_state* s, int32_t* entering);
@@ -203,6 +209,8 @@ typedef struct lpx_solve_options {
   int32_t* perm_out;            /* optional int32[n+m]: final slot -> variable id                         */
   double* x_out;                /* optional double[n]: primal solution (basic slot -> b[i], else 0)       */
   lpx_state** keep_state;       /* optional: receive the final LPState handle instead of destroying it    */
+  int32_t pricing;              /* 0 = the reference's entering rule (default); 1 = Dantzig, see            */
+  int32_t reserved;             /* lpx_state_set_pricing                                                   */
 } lpx_solve_options;
 
 /* BigDecimal LPSolver.solve(LPStandardForm stForm)                      LPSolver.java:78

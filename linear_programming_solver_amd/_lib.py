@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, "liblpx.so")
 OPTIMAL, UNBOUNDED, INFEASIBLE, AUX_UNBOUNDED, NO_DEGENERATE_PIVOT, BAD_ARGUMENT, RESTORE_INDEX_FAULT, \
     DEVICE_ERROR, DIVIDE_BY_ZERO, PIVOT_LIMIT = range(10)
 CAND_HEADER = 8
+PRICING = {"reference": 0, "first-positive": 0, "dantzig": 1, 0: 0, 1: 1}
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
@@ -41,6 +42,8 @@ class SolveOptions(C.Structure):
         ("perm_out", ip),
         ("x_out", dp),
         ("keep_state", C.POINTER(C.c_void_p)),
+        ("pricing", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -58,6 +61,7 @@ SYMBOLS = [
     ("lpx_state_destroy", None, [C.c_void_p]),
     ("lpx_state_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
     ("lpx_state_use_masked_stream", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("lpx_state_set_pricing", C.c_int, [C.c_void_p, C.c_int32]),
     ("lpx_get_entering", C.c_int, [C.c_void_p, ip]),
     ("lpx_get_leaving", C.c_int, [C.c_void_p, C.c_int32, ip, dp]),
     ("lpx_pivot", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -71,6 +71,7 @@ struct lpx_state {
   Buffers B{};
   Geometry g{};
   bool nontemporal = false;
+  int pricing = 0;                  // 0 = reference rule (first positive), 1 = Dantzig (opt-in extension)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
   // look-ahead pipeline of the sharded loop: parameter ring, second pivot-row buffer, second stream
   LpxCtl* ring = nullptr;           // 2 device blocks
@@ -340,6 +341,18 @@ extern "C" int lpx_profile_read(lpx_state* s, int64_t* launches, double* total_m
   return 0;
 }
 
+// entering scan at the start of a loop / for getEntering(), honouring the handle's pricing rule
+static void launch_seed_entering(lpx_state* s) {
+  if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, true, s->stream);
+  else lpxk::launch_entering(s->B, s->n, s->stream);
+}
+
+extern "C" int lpx_state_set_pricing(lpx_state* s, int32_t pricing) {
+  if (!s || (pricing != 0 && pricing != 1)) return fail(LPX_BAD_ARGUMENT, "lpx_state_set_pricing: bad argument");
+  s->pricing = pricing;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ step API
 static int require_single(lpx_state* s, const char* who) {
   if (!s) return fail(LPX_BAD_ARGUMENT, std::string(who) + ": NULL state");
@@ -364,7 +377,7 @@ extern "C" int lpx_get_entering(lpx_state* s, int32_t* entering) {
   if (!s || !entering) return fail(LPX_BAD_ARGUMENT, "lpx_get_entering: NULL argument");
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = set_running(s, -1, -1)) return rc;
-  lpxk::launch_entering(s->B, s->n, s->stream);
+  launch_seed_entering(s);
   HIP_TRY(hipGetLastError());
   if (int rc = sync_ctl_to_host(s)) return rc;
   *entering = s->h_ctl->e_next;
@@ -408,7 +421,7 @@ extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivot
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = set_running(s, max_pivots, track_slot ? *track_slot : -1)) return rc;
   // seed: entering scan + strided column gather / partials for the first pivot
-  lpxk::launch_entering(s->B, s->n, s->stream);
+  launch_seed_entering(s);
   lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, -1, s->stream);
   HIP_TRY(hipGetLastError());
 
@@ -433,6 +446,7 @@ extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivot
     }
     for (int k = 0; k < nb; k++) {
       lpxk::launch_select_pivot(s->B, s->n, s->m_global, s->g, -1, -1, s->stream);
+      if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, false, s->stream);
       if (k == nb - 1 && max_pivots >= 0 && enqueued + k + 1 == max_pivots + 1) break;  // last one only reports LIMIT
       if (int rc = launch_update_profiled(s)) return rc;
     }
@@ -480,6 +494,7 @@ extern "C" int lpx_shard_commit(lpx_state* s, const double* d_gathered, int32_t 
   if (!s || !d_gathered || nranks < 1) return fail(LPX_BAD_ARGUMENT, "lpx_shard_commit: bad argument");
   HIP_TRY(hipSetDevice(s->device));
   lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, s->B.prow, s->B.ctl, -1, s->stream);
+  if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, false, s->stream);
   if (int rc = launch_update_profiled(s)) return rc;
   return 0;
 }
@@ -555,6 +570,7 @@ extern "C" int lpx_shard_decide(lpx_state* s, const double* d_gathered, int32_t 
   double* prow = slot ? s->prow2 : s->B.prow;
   // parity = slot^1 makes k_update(slot) read col[slot], the column k_peek produced for this pivot
   lpxk::launch_commit(s->B, s->n, s->m_global, d_gathered, nranks, prow, &s->ring[slot], slot ^ 1, comm_of(s));
+  if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, false, comm_of(s));
   HIP_TRY(hipGetLastError());
   if (comm_of(s) != s->stream) {
     HIP_TRY(hipEventRecord(s->ev_decide, comm_of(s)));
@@ -576,7 +592,7 @@ extern "C" int lpx_shard_begin(lpx_state* s, int64_t max_pivots, int32_t track_s
   if (s->comm_stream) HIP_TRY(hipStreamSynchronize(s->comm_stream));
   if (int rc = set_running(s, max_pivots, track_slot)) return rc;
   HIP_TRY(hipMemsetAsync(s->ring, 0, 2 * sizeof(LpxCtl), s->stream));
-  lpxk::launch_entering(s->B, s->n, s->stream);
+  launch_seed_entering(s);
   lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, -1, s->stream);
   HIP_TRY(hipGetLastError());
   return 0;

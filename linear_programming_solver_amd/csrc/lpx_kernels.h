@@ -58,6 +58,8 @@ struct Buffers {
 
 // ---- launch wrappers (all asynchronous on `s`) -------------------------------------------------------------
 void launch_entering(const Buffers& B, int n, hipStream_t s);
+// opt-in Dantzig pricing: overrides ctl->e_next after a decision (seed: at the start of a loop)
+void launch_entering_dantzig(const Buffers& B, int n, bool seed, hipStream_t s);
 // forced_e >= 0: use it as e_next instead of ctl->e_next (step API)
 void launch_ratio_gather(const Buffers& B, int m_local, int row0, const Geometry& g, int forced_e, hipStream_t s);
 void launch_reduce_partials(const Buffers& B, const Geometry& g, hipStream_t s);

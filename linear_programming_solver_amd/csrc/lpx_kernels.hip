@@ -91,6 +91,31 @@ __global__ __launch_bounds__(1024) void k_entering(const double* __restrict__ c,
   }
 }
 
+// Opt-in Dantzig pricing (an extension of this build; NOT the reference's rule): entering
+// slot = argmax c[j] over c[j] > 1e-9, lowest slot on ties.  Runs as one extra small launch after the pivot
+// decision and overrides ctl->e_next (k_select_pivot / k_commit have already set status = OPTIMAL when no
+// c[j] > 1e-9 exists, which is rule-independent).  `seed` = 1: also decide OPTIMAL (start of a loop).
+__global__ __launch_bounds__(1024) void k_entering_dantzig(const double* __restrict__ c, int n, LpxCtl* ctl,
+                                                           int seed) {
+  __shared__ RatioRow sh[16];
+  if (ctl->status != kRunning) return;
+  RatioRow best{-kInf, INT_MAX, 0};  // reuse the (value,index) lexmin machinery on (-c[j], j)
+  best.ratio = kInf;
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const double cj = c[j];
+    if (cj > kEps) {
+      const RatioRow cand{-cj, j, 0};
+      if (cand.ratio < best.ratio) best = cand;  // j ascends per thread: strict < keeps the lowest slot
+    }
+  }
+  best = rr_block_min(best, sh);
+  if (threadIdx.x == 0) {
+    const bool none = best.row == INT_MAX;
+    ctl->e_next = none ? -1 : best.row;
+    if (none && seed) ctl->status = 0 /* LPX_OPTIMAL */;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ k_ratio_gather
 // Seeds the pipeline: strided gather of column e_next into col[parity] plus the per-tile partials of
 // getLeaving (LPState.java:287-305).  Only used for the first pivot of a loop and by the step API; inside
@@ -704,6 +729,11 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ A,
 // ------------------------------------------------------------------------------------------------ launchers
 void launch_entering(const Buffers& B, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_entering, dim3(1), dim3(1024), 0, s, B.c, n, B.ctl);
+}
+
+void launch_entering_dantzig(const Buffers& B, int n, bool seed, hipStream_t s) {
+  // 256 threads: this kernel may run beside the row update on the comm stream (look-ahead pipeline)
+  hipLaunchKernelGGL(k_entering_dantzig, dim3(1), dim3(256), 0, s, B.c, n, B.ctl, seed ? 1 : 0);
 }
 
 void launch_ratio_gather(const Buffers& B, int m_local, int row0, const Geometry& g, int forced_e, hipStream_t s) {

@@ -146,6 +146,9 @@ extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, con
   lpx_state* s = nullptr;
   if (int rc = alloc(m, n_cap, n_cap, o.device, &s)) { res->status = rc; return rc; }
   guard.s = s;
+  if (o.pricing != 0) {
+    if (int rc = lpx_state_set_pricing(s, o.pricing)) { res->status = rc; return rc; }
+  }
   hipStream_t st = stream(s);
   lpxk::Buffers& B = buffers(s);
   double t_pivots = 0.0;

@@ -30,9 +30,12 @@ class SolveInfo:
 
 
 class LPSolver:
-    def __init__(self, device=0, max_pivots=-1):
+    def __init__(self, device=0, max_pivots=-1, pricing="reference"):
+        """pricing="reference": the reference's first-positive rule (default, parity with the Java solver);
+        pricing="dantzig": opt-in largest-coefficient rule (same optimum, ~10x fewer pivots, no pivot parity)."""
         self.device = int(device)
         self.max_pivots = int(max_pivots)
+        self.pricing = _lib.PRICING[pricing]
         self.last = None
 
     def solve(self, st_form, restore_order=None):
@@ -47,6 +50,7 @@ class LPSolver:
         opts.device = self.device
         opts.has_variable_names = 1 if st_form.has_variable_names() else 0
         opts.max_pivots = self.max_pivots
+        opts.pricing = self.pricing
         order = None
         if restore_order is not None:
             order = np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))

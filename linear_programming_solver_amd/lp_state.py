@@ -11,7 +11,7 @@ from .errors import raise_for_status
 
 class LPState:
     def __init__(self, A, b, c, v=0.0, variables=None, coefficients=None, m=None, n=None, device=0,
-                 perm=None, row0=0, m_global=None):
+                 perm=None, row0=0, m_global=None, pricing="reference"):
         """new LPState(A, b, c, v, variables, coefficients, m, n)  (LPState.java:101-112).
         `variables`/`coefficients` are the reference's name maps (slot -> name / name -> slot); they are
         kept on the host and permuted from the device's slot permutation on demand."""
@@ -36,6 +36,10 @@ class LPState:
             raise_for_status(rc)
         self._h = h
         self._L = L
+        if _lib.PRICING[pricing]:   # opt-in Dantzig rule: leaves the reference's pivot sequence on purpose
+            rc = L.lpx_state_set_pricing(h, _lib.PRICING[pricing])
+            if rc:
+                raise_for_status(rc)
 
     # -- lifecycle
     def close(self):

@@ -35,7 +35,7 @@ class HipShardEngine:
     current stream."""
 
     def __init__(self, A_local, b_local, c, row0, m_global, nranks, device=0, perm=None, v=0.0, stream=None,
-                 comm_stream=None, reserve_xcds=1):
+                 comm_stream=None, reserve_xcds=1, pricing="reference"):
         import torch
         self.torch = torch
         L = _lib.lib()
@@ -56,6 +56,10 @@ class HipShardEngine:
         if rc:
             raise_for_status(rc)
         self._h = h
+        if _lib.PRICING[pricing]:
+            rc = L.lpx_state_set_pricing(h, _lib.PRICING[pricing])
+            if rc:
+                raise_for_status(rc)
         dev = torch.device("cuda", self.device)
         rec = _lib.CAND_HEADER + self.n
         self.cand = torch.zeros(rec, dtype=torch.float64, device=dev)

@@ -156,6 +156,13 @@ void* orc_state_new(int kind, int m, int n, const double* A, const double* b, co
 
 void orc_state_free(void* p) { delete (Handle*)p; }
 
+// 0 = reference rule (first positive), 1 = Dantzig (opt-in extension, see lp_oracle.hpp)
+void orc_state_set_pricing(void* p, int pricing) {
+  Handle* h = (Handle*)p;
+  h->sd.pricing = pricing;
+  h->sf.pricing = pricing;
+}
+
 int orc_get_entering(void* p) {
   Handle* h = (Handle*)p;
   return h->kind == 0 ? h->sd.get_entering() : h->sf.get_entering();
@@ -246,7 +253,7 @@ template <> std::string objective_text<double>(const double& v) { return round6_
 template <class T>
 Handle* solve_impl(int kind, int m, int n, const double* A, const double* b, const double* c, int maximize,
                    const int32_t* restore_order, int64_t max_pivots, int threads, orc_result* res,
-                   int32_t* trace_out, int64_t trace_cap) {
+                   int32_t* trace_out, int64_t trace_cap, int pricing) {
   typedef Num<T> N;
   std::vector<T> Av((size_t)m * n), bv(m), cv(n);
   for (size_t i = 0; i < Av.size(); i++) Av[i] = N::from_double(A[i]);
@@ -259,7 +266,7 @@ Handle* solve_impl(int kind, int m, int n, const double* A, const double* b, con
   auto t0 = std::chrono::steady_clock::now();
   int status;
   try {
-    solve<T>(m, n, Av, bv, cv, maximize != 0, order, max_pivots, threads, trace_out != nullptr, out);
+    solve<T>(m, n, Av, bv, cv, maximize != 0, order, max_pivots, threads, trace_out != nullptr, out, pricing);
     status = out.status;
   } catch (const DivideByZero&) {
     status = LPX_DIVIDE_BY_ZERO;
@@ -300,12 +307,18 @@ extern "C" {
 
 // Returns a state handle holding the final LPState (or the aux LPState if phase 1 failed); the caller
 // frees it with orc_state_free.  trace_out: 3 ints per pivot (phase, entering, leaving), may be NULL.
+void* orc_solve2(int kind, int m, int n, const double* A, const double* b, const double* c, int maximize,
+                 const int32_t* restore_order, int64_t max_pivots, int threads, orc_result* res,
+                 int32_t* trace_out, int64_t trace_cap, int pricing) {
+  if (kind == 0)
+    return solve_impl<Dec>(kind, m, n, A, b, c, maximize, restore_order, max_pivots, threads, res, trace_out, trace_cap, pricing);
+  return solve_impl<double>(kind, m, n, A, b, c, maximize, restore_order, max_pivots, threads, res, trace_out, trace_cap, pricing);
+}
+
 void* orc_solve(int kind, int m, int n, const double* A, const double* b, const double* c, int maximize,
                 const int32_t* restore_order, int64_t max_pivots, int threads, orc_result* res,
                 int32_t* trace_out, int64_t trace_cap) {
-  if (kind == 0)
-    return solve_impl<Dec>(kind, m, n, A, b, c, maximize, restore_order, max_pivots, threads, res, trace_out, trace_cap);
-  return solve_impl<double>(kind, m, n, A, b, c, maximize, restore_order, max_pivots, threads, res, trace_out, trace_cap);
+  return orc_solve2(kind, m, n, A, b, c, maximize, restore_order, max_pivots, threads, res, trace_out, trace_cap, 0);
 }
 
 // solveAuxLP(auxLP, indexOfx0, minInB) on an existing aux state (LPSolver.java:135): returns x0CurrentIndex,

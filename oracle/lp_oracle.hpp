@@ -93,6 +93,10 @@ template <class T> struct State {
   std::vector<T> b, c;
   T v;
   std::vector<int32_t> perm;  // slot -> variable id (n+m entries); empty == "no variable names"
+  // 0 = the reference's rule (first slot with c > eps, LPState.java:274-285).  1 = Dantzig (largest c, lowest
+  // slot on ties): an OPT-IN extension of this build that deliberately leaves the
+  // reference's pivot sequence; it exists in the oracle only so that the GPU's opt-in mode has a checker.
+  int pricing = 0;
 
   T& a(int i, int j) { return A[(size_t)i * n + j]; }
   const T& a(int i, int j) const { return A[(size_t)i * n + j]; }
@@ -100,6 +104,12 @@ template <class T> struct State {
   // LPState.java:274-285
   int get_entering() const {
     const T eps = N::eps();
+    if (pricing == 1) {
+      int best = -1;
+      for (int i = 0; i < n; i++)
+        if (N::cmp(c[i], eps) > 0 && (best < 0 || N::cmp(c[i], c[best]) > 0)) best = i;
+      return best;
+    }
     for (int i = 0; i < n; i++)
       if (N::cmp(c[i], eps) > 0) return i;
     return -1;
@@ -337,9 +347,10 @@ int restore_initial_lp(const State<T>& aux, const std::vector<T>& c0, int n, int
 template <class T>
 void solve(int m, int n, const std::vector<T>& A_in, const std::vector<T>& b_in,
            const std::vector<T>& c_in, bool maximize, std::vector<int32_t> restore_order,
-           int64_t max_pivots, int threads, bool want_trace, SolveOut<T>& out) {
+           int64_t max_pivots, int threads, bool want_trace, SolveOut<T>& out, int pricing = 0) {
   typedef Num<T> N;
   std::vector<PivotRecord>* trace = want_trace ? &out.trace : nullptr;
+  out.final_state.pricing = pricing;
   std::vector<T> c0 = c_in;
   out.negate_result = !maximize;
   if (!maximize)
@@ -355,6 +366,7 @@ void solve(int m, int n, const std::vector<T>& A_in, const std::vector<T>& b_in,
   } else {
     out.phase1_used = true;
     State<T> aux;
+    aux.pricing = pricing;
     convert_into_aux_lp(m, n, A_in, b_in, aux);                                    // :128
     const int na = aux.n;
     int x0 = -1;
@@ -381,6 +393,7 @@ void solve(int m, int n, const std::vector<T>& A_in, const std::vector<T>& b_in,
     out.x0_slot = x0;
     if (restore_order.empty()) restore_order = java_default_name_order(n);
     int rs = restore_initial_lp(aux, c0, n, x0, restore_order, st);                // :179
+    st.pricing = pricing;
     if (rs != LPX_OPTIMAL) { out.status = rs; out.v = aux.v; out.final_state = aux; return; }
   }
   int64_t lim2 = max_pivots < 0 ? -1 : (max_pivots - out.pivots1);

@@ -79,6 +79,10 @@ def lib():
     L.orc_solve.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, C.c_int, ip, C.c_int64, C.c_int,
                             C.POINTER(OrcResult), ip, C.c_int64]
     L.orc_solve.restype = C.c_void_p
+    L.orc_solve2.argtypes = L.orc_solve.argtypes + [C.c_int]
+    L.orc_solve2.restype = C.c_void_p
+    L.orc_state_set_pricing.argtypes = [C.c_void_p, C.c_int]
+    L.orc_state_set_pricing.restype = None
     L.orc_min_in_b.argtypes = [C.c_int, C.c_int, dp]
     L.orc_solve_aux_lp.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_convert_into_aux_lp.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp]
@@ -137,7 +141,7 @@ def java_default_name_order(n):
 class State:
     """Mirror of the reference's LPState over the oracle (LPState.java)."""
 
-    def __init__(self, A, b, c, v=0.0, perm=None, kind=DEC15, with_perm=True, _handle=None):
+    def __init__(self, A, b, c, v=0.0, perm=None, kind=DEC15, with_perm=True, _handle=None, pricing=0):
         self.kind = kind
         if _handle is not None:
             self._h = _handle
@@ -153,6 +157,8 @@ class State:
         m_, n_, hp = C.c_int32(), C.c_int32(), C.c_int32()
         lib().orc_state_dims(self._h, C.byref(m_), C.byref(n_), C.byref(hp))
         self.m, self.n, self.has_perm = m_.value, n_.value, bool(hp.value)
+        if pricing:
+            lib().orc_state_set_pricing(self._h, int(pricing))
 
     def close(self):
         if self._h:
@@ -237,7 +243,7 @@ def restore_initial_lp(aux_state, initial_c, x0_slot, order):
 
 
 def solve(A, b, c, maximize=True, kind=DEC15, restore_order=None, max_pivots=-1, threads=1,
-          want_trace=True, trace_cap=1 << 20):
+          want_trace=True, trace_cap=1 << 20, pricing=0):
     """LPSolver.solve (LPSolver.java:78).  Returns (result dict, final State)."""
     b = _f64(b)
     c = _f64(c)
@@ -246,9 +252,9 @@ def solve(A, b, c, maximize=True, kind=DEC15, restore_order=None, max_pivots=-1,
     ro = None if restore_order is None else np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))
     res = OrcResult()
     tr = np.zeros((trace_cap if want_trace else 1, 3), dtype=np.int32)
-    h = lib().orc_solve(kind, m, n, _dp(A), _dp(b), _dp(c), 1 if maximize else 0,
-                        None if ro is None else _ip(ro), int(max_pivots), int(threads), C.byref(res),
-                        _ip(tr) if want_trace else None, trace_cap)
+    h = lib().orc_solve2(kind, m, n, _dp(A), _dp(b), _dp(c), 1 if maximize else 0,
+                         None if ro is None else _ip(ro), int(max_pivots), int(threads), C.byref(res),
+                         _ip(tr) if want_trace else None, trace_cap, int(pricing))
     st = State(None, None, None, kind=kind, _handle=h)
     out = {
         "status": res.status, "phase1_used": bool(res.phase1_used), "objective": res.objective,

@@ -593,3 +593,55 @@ def test_leading_dimension_and_lda_validation(lps):
                               C.byref(h2)) == _lib.BAD_ARGUMENT
     assert L.lpx_state_create(m, n, buf.ctypes.data_as(_lib.dp), lda, b.ctypes.data_as(_lib.dp),
                               c.ctypes.data_as(_lib.dp), 0.0, None, 0, m, 99, C.byref(h2)) == _lib.BAD_ARGUMENT
+
+
+# ------------------------------------------------------------------------------------ opt-in Dantzig pricing
+def test_dantzig_pricing_bit_exact_vs_oracle_with_the_same_rule(lps, oracle):
+    """pricing="dantzig" (largest c[j], lowest slot on ties) is an opt-in extension that leaves the reference's
+    pivot sequence; its checker is the oracle running the same rule."""
+    import torch
+    from linear_programming_solver_amd.sharded import HipShardEngine, LocalExchange, row_block, sharded_simplex_loop
+    for (m, n) in [(60, 90), (200, 1100), (257, 300)]:
+        A, b, c = dense_lp(m, n, seed=31 * m + n)
+        st = lps.LPState(A, b, c, pricing="dantzig")
+        ref = oracle.State(A, b, c, kind=oracle.FP64, pricing=1)
+        assert st.get_entering() == ref.get_entering() == int(np.argmax(c))
+        status, pivots, _ = st.simplex_loop()
+        want = ref.simplex_loop()
+        assert (status, pivots) == (want["status"], want["pivots"])
+        assert_state_bits_equal(st.read(), ref.read(), "dantzig %dx%d" % (m, n))
+        first = oracle.State(A, b, c, kind=oracle.FP64).simplex_loop()
+        assert pivots < first["pivots"]                       # the point of the option
+        st.close()
+        for lookahead in (False, True):                        # and on row-block shards, both loop forms
+            stream, comm = torch.cuda.Stream(), torch.cuda.Stream()
+            engines = []
+            for r in range(3):
+                r0, r1 = row_block(m, 3, r)
+                engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, 3, stream=stream, comm_stream=comm,
+                                              pricing="dantzig"))
+            s2, p2, _ = sharded_simplex_loop(engines, LocalExchange(), poll_every=5, lookahead=lookahead)
+            assert (s2, p2) == (want["status"], want["pivots"])
+            got = np.vstack([e.read()[0] for e in engines])
+            assert np.array_equal(bits(got), bits(ref.read()[0]))
+            for e in engines:
+                e.close()
+
+
+def test_dantzig_pricing_through_solve_with_phase1(lps, oracle):
+    rng = np.random.default_rng(8)
+    for t in range(12):
+        m, n = int(rng.integers(3, 30)), int(rng.integers(3, 30))
+        A = np.round(rng.uniform(-3, 5, size=(m, n)), 3)
+        b = np.round(rng.uniform(-2, 9, size=m), 3)
+        c = np.round(rng.uniform(-2, 4, size=n), 3)
+        want, wst = oracle.solve(A, b, c, True, kind=oracle.FP64, want_trace=False, pricing=1)
+        solver = lps.LPSolver(pricing="dantzig")
+        try:
+            solver.solve(lps.LPStandardForm(A, b, c, maximize=True))
+        except (lps.LPException, IndexError):
+            pass
+        got = solver.last
+        assert (got.status, got.pivots_phase1, got.pivots_phase2, got.x0_slot) == \
+            (want["status"], want["pivots1"], want["pivots2"], want["x0_slot"]), t
+        assert bits(np.array([got.objective]))[0] == bits(np.array([want["objective"]]))[0], t
