@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("LPX_BENCH_WORKLOAD", "cfg4"), choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the extra cfg3 measurement of the default N=1 run")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--poll-every", type=int, default=32)
     ap.add_argument("--event-every", type=int, default=8,
@@ -274,6 +275,29 @@ def main():
             "host_gen_s": t_gen,
             "host_upload_s": t_up,   # hipMalloc + PCIe upload of this rank's tableau; outside the timed region
         }
+        if world == 1 and not sharded and args.workload == "cfg4" and not args.no_cfg3:
+            # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
+            # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)
+            st.close()
+            m3, n3 = WORKLOADS["cfg3"]
+            A3, b3, c3 = gen_rows(m3, n3, args.seed, 0, m3)
+            st3 = LPState(A3, b3, c3, device=local_rank)
+            st3.simplex_loop(max_pivots=W)
+            st3.profile_enable(args.event_every)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            s3, p3, _ = st3.simplex_loop(max_pivots=K)
+            torch.cuda.synchronize()
+            e3 = time.perf_counter() - t0
+            l3, ms3 = st3.profile_read()
+            st3.close()
+            if p3 == K and l3 > 0:
+                ach3 = 16.0 * m3 * n3 / (ms3 / l3 * 1e-3) / 1e9
+                line["cfg3"] = {"workload": "cfg3: m=8192 n=16384, %d pivots after %d warm-up" % (K, W),
+                                "value": K / e3, "unit": "pivots/s", "ms_per_step": 1e3 * e3 / K,
+                                "roofline": {"bound": "hbm", "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": ach3 / HBM_PEAK_GBS, "avg_kernel_ms": ms3 / l3,
+                                             "whole_pivot_frac": 16.0 * m3 * n3 * (K / e3) / (HBM_PEAK_GBS * 1e9)}}
         if world == 1 and not args.no_cpu_baseline:
             rows_s = min(m, 8192)
             line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))
