@@ -108,6 +108,7 @@ static Geometry choose_geometry(int m, int64_t ld) {
   g.nstrips = (int)((ld + W - 1) / W);
   int R = env_int("LPX_ROWS_PER_TILE", 2);
   if (R < 2) R = 2;
+  if (R > 256) R = 256;  // the seed/peek kernels emit one partial per 256 rows into the same buffer
   if (R & 1) R += 1;  // rows are processed in pairs
   g.rows_per_tile = R;
   g.ntiles = m > 0 ? (m + R - 1) / R : 0;

@@ -123,24 +123,26 @@ __global__ __launch_bounds__(1024) void k_entering_dantzig(const double* __restr
 __global__ __launch_bounds__(256) void k_ratio_gather(const double* __restrict__ A, int64_t ld,
                                                       const double* __restrict__ b, int m_local, int row0,
                                                       double* col0, double* col1, RatioRow* partial,
-                                                      const LpxCtl* __restrict__ ctl, int rows_per_tile,
+                                                      const LpxCtl* __restrict__ ctl, int nparts,
                                                       int forced_e) {
   __shared__ RatioRow sh[4];
   if (ctl->status != kRunning) return;
   const int e = forced_e >= 0 ? forced_e : ctl->e_next;
   if (e < 0) return;
   double* col = ctl->parity ? col1 : col0;
-  const int r0 = blockIdx.x * rows_per_tile;
-  const int r1 = min(m_local, r0 + rows_per_tile);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // one row per thread
   RatioRow best = rr_none();
-  for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
+  if (i < m_local) {
     const double a = A[(int64_t)i * ld + e];
     col[i] = a;
     const double r = ratio_of(a, b[i]);
-    if (r < best.ratio) best = RatioRow{r, row0 + i, 0};  // rows ascend per thread: strict < keeps the lowest
+    if (r < kInf) best = RatioRow{r, row0 + i, 0};
   }
   best = rr_block_min(best, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = best;
+  // the consumers fold all `nparts` (= k_update's tile count) slots: blank the ones this grid does not produce
+  for (int k = gridDim.x + blockIdx.x * blockDim.x + threadIdx.x; k < nparts; k += gridDim.x * blockDim.x)
+    partial[k] = rr_none();
 }
 
 // getLeaving() of the step API: fold the partials into ctl->l / ctl->ratio, no pivot.
@@ -738,8 +740,9 @@ void launch_entering_dantzig(const Buffers& B, int n, bool seed, hipStream_t s) 
 
 void launch_ratio_gather(const Buffers& B, int m_local, int row0, const Geometry& g, int forced_e, hipStream_t s) {
   if (g.ntiles <= 0) return;
-  hipLaunchKernelGGL(k_ratio_gather, dim3(g.ntiles), dim3(256), 0, s, B.A, B.ld, B.b, m_local, row0, B.col[0],
-                     B.col[1], B.partial, B.ctl, g.rows_per_tile, forced_e);
+  const int nblk = (m_local + 255) / 256;  // <= ntiles: choose_geometry caps a tile at 256 rows
+  hipLaunchKernelGGL(k_ratio_gather, dim3(nblk), dim3(256), 0, s, B.A, B.ld, B.b, m_local, row0, B.col[0],
+                     B.col[1], B.partial, B.ctl, g.ntiles, forced_e);
 }
 
 void launch_reduce_partials(const Buffers& B, const Geometry& g, hipStream_t s) {
