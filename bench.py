@@ -34,6 +34,8 @@ WORKLOADS = {
     "cfg2": (1024, 2048),     # cache-resident; parity config, not a roofline config
     "cfg3": (8192, 16384),    # 1 GiB tableau, 2.147 GB algorithmic bytes per pivot
     "cfg4": (32768, 16384),   # 4 GiB tableau, 8.59 GB per pivot; the 1/2/4/8-GPU scaling config
+    "cfg4_shard8": (4096, 16384),   # what ONE rank streams per pivot when cfg4 is sharded over 8 GPUs
+    "cfg4_shard2": (16384, 16384),
 }
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
 CHUNK = 1024
