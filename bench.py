@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--no-lookahead", action="store_true",
                     help="sharded runs: plain propose/all-gather/commit per pivot instead of the software-pipelined "
                          "form that overlaps the exchange of pivot t+1 with the row update of pivot t")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("LPX_BENCH_PIPELINE", "2")), choices=[1, 2],
+                    help="sharded look-ahead form: 1 = in-place update, peek before it; 2 = out-of-place update "
+                         "between two tableau buffers, peek + exchange + decision all beside the running update")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-block shard engine + the torch.distributed collective even at N=1")
     args = ap.parse_args()
@@ -223,7 +226,7 @@ def main():
         objective = st.v
         eng = st
     else:
-        eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank)
+        eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank, pipeline=args.pipeline)
         t_up = time.perf_counter() - t_up
         ex = DistExchange()
         status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=W, poll_every=args.poll_every,
@@ -266,7 +269,8 @@ def main():
             "config": {"workload": "%s: dense random LP m=%d n=%d fp64 (A~U(0,1), b=(n/4)U(1,2), c~U(0,1), max), "
                                    "first-positive entering rule, %d pivots after %d warm-up" % (args.workload, m, n, K, W),
                        "m": m, "n": n, "seed": args.seed,
-                       "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot%s" % (world, "" if args.no_lookahead else ", look-ahead pipelined")},
+                       "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot%s" % (
+                           world, "" if args.no_lookahead else ", look-ahead pipeline %d" % args.pipeline)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_update", "avg_kernel_ms": avg_ms, "launches_sampled": launches,

@@ -173,6 +173,13 @@ int lpx_shard_probe(lpx_state* s, const double* d_gathered, int32_t nranks);
  * Parameter blocks, pivot rows and pivot columns are double-buffered by slot.  The library records/waits
  * the cross-stream events; without lpx_shard_set_comm_stream everything runs on the main stream. */
 int lpx_shard_set_comm_stream(lpx_state* s, void* hip_stream);
+/* mode 1 (default): look-ahead as above, row update in place, the peek runs on the main stream before the
+ * update.  mode 2: fully overlapped — a second tableau buffer is allocated and the row update becomes
+ * out-of-place (same HBM traffic), so the peek of pivot t+1 also runs on the comm stream, beside update(t),
+ * reading the buffer update(t) reads; the critical path per pivot is then the row update alone.  Same host
+ * call sequence in both modes.  In mode 2 the loop must be polled to a final status before the state is
+ * read or another loop is started (the library then points the handle at the buffer holding the result). */
+int lpx_shard_set_pipeline(lpx_state* s, int32_t mode);
 int lpx_shard_peek(lpx_state* s, double* d_candidate, int32_t slot, int32_t pending);
 int lpx_shard_decide(lpx_state* s, const double* d_gathered, int32_t nranks, int32_t slot);
 int lpx_shard_update(lpx_state* s, int32_t slot);

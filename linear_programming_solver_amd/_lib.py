@@ -76,6 +76,7 @@ SYMBOLS = [
     ("lpx_shard_commit", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     ("lpx_shard_probe", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     ("lpx_shard_set_comm_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("lpx_shard_set_pipeline", C.c_int, [C.c_void_p, C.c_int32]),
     ("lpx_shard_peek", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("lpx_shard_decide", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("lpx_shard_update", C.c_int, [C.c_void_p, C.c_int32]),

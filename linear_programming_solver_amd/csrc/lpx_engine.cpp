@@ -77,7 +77,16 @@ struct lpx_state {
   LpxCtl* ring = nullptr;           // 2 device blocks
   double* prow2 = nullptr;
   hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_peek = nullptr, ev_decide = nullptr;
+  hipEvent_t ev_peek = nullptr, ev_decide = nullptr, ev_upd = nullptr;
+  // pipeline = 2: fully overlapped form — out-of-place row update between two tableau buffers so that the peek
+  // of pivot t+1 (comm stream) reads the un-updated tableau while update(t) streams (main stream)
+  int pipeline = 1;
+  double* A2 = nullptr;             // spare tableau / b of the out-of-place update (B.A/A2 and B.b/b2 swap roles)
+  double* A_base[2] = {nullptr, nullptr};   // the two hipMalloc'ed tableau allocations, for hipFree
+  double* b_base[2] = {nullptr, nullptr};
+  double* b2 = nullptr;
+  bool upd_recorded = false;
+  bool settled = true;              // B.A/B.b point at the buffer that holds the current tableau
   unsigned long long* d_sum = nullptr;
   // row-update profiling (HIP events on `stream`)
   int prof = 0;                     // 0 = off, N = bracket every N-th row-update launch with events
@@ -131,8 +140,10 @@ static void free_state(lpx_state* s) {
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
-  (void)hipFree(s->B.A);
-  (void)hipFree(s->B.b);
+  (void)hipFree(s->A_base[0]);
+  (void)hipFree(s->A_base[1]);
+  (void)hipFree(s->b_base[0]);
+  (void)hipFree(s->b_base[1]);
   (void)hipFree(s->B.c);
   (void)hipFree(s->B.prow);
   (void)hipFree(s->B.col[0]);
@@ -143,6 +154,8 @@ static void free_state(lpx_state* s) {
   (void)hipFree(s->d_sum);
   (void)hipFree(s->ring);
   (void)hipFree(s->prow2);
+  if (s->ev_upd) (void)hipEventDestroy(s->ev_upd);
+
   if (s->ev_peek) (void)hipEventDestroy(s->ev_peek);
   if (s->ev_decide) (void)hipEventDestroy(s->ev_decide);
   if (s->h_ctl) (void)hipHostFree(s->h_ctl);
@@ -177,7 +190,9 @@ static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, 
     if (_e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, std::string("hipMemset: ") + hipGetErrorString(_e)); } \
   } while (0)
   ALLOC(s->B.A, mp * ld, double);
+  s->A_base[0] = s->B.A;
   ALLOC(s->B.b, mp, double);
+  s->b_base[0] = s->B.b;
   ALLOC(s->B.c, ld, double);
   ALLOC(s->B.prow, ld, double);
   ALLOC(s->B.col[0], mp, double);
@@ -196,6 +211,7 @@ static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, 
   if (e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, "hipStreamCreate failed"); }
   s->stream = s->own_stream;
   if (hipEventCreateWithFlags(&s->ev_peek, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_upd, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_decide, hipEventDisableTiming) != hipSuccess) {
     free_state(s);
     return fail(LPX_DEVICE_ERROR, "hipEventCreate failed");
@@ -285,9 +301,11 @@ extern "C" int lpx_state_dims(const lpx_state* s, int32_t* m_local, int32_t* n, 
 }
 
 // ------------------------------------------------------------------------------------------------ launches
-static int launch_update_profiled(lpx_state* s, const double* prow = nullptr, const LpxCtl* up = nullptr) {
+static int launch_update_profiled(lpx_state* s, const double* prow = nullptr, const LpxCtl* up = nullptr,
+                                  const Buffers* Bin = nullptr, double* A_out = nullptr, double* b_out = nullptr) {
   if (!prow) prow = s->B.prow;
   if (!up) up = s->B.ctl;
+  const Buffers& BB = Bin ? *Bin : s->B;
   if (s->prof > 0 && (s->prof_seq++ % s->prof) == 0) {
     if (s->ev_used + 2 > s->ev.size()) {
       for (int k = 0; k < 512; k++) {
@@ -297,11 +315,11 @@ static int launch_update_profiled(lpx_state* s, const double* prow = nullptr, co
       }
     }
     HIP_TRY(hipEventRecord(s->ev[s->ev_used], s->stream));
-    lpxk::launch_update(s->B, s->m, s->n, s->row0, s->g, s->nontemporal, prow, up, s->stream);
+    lpxk::launch_update(BB, s->m, s->n, s->row0, s->g, s->nontemporal, prow, up, A_out, b_out, s->stream);
     HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], s->stream));
     s->ev_used += 2;
   } else {
-    lpxk::launch_update(s->B, s->m, s->n, s->row0, s->g, s->nontemporal, prow, up, s->stream);
+    lpxk::launch_update(BB, s->m, s->n, s->row0, s->g, s->nontemporal, prow, up, A_out, b_out, s->stream);
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -549,11 +567,49 @@ extern "C" int lpx_shard_set_comm_stream(lpx_state* s, void* hip_stream) {
 
 static hipStream_t comm_of(lpx_state* s) { return s->comm_stream ? s->comm_stream : s->stream; }
 
+// physical tableau/b of logical slot k in the overlapped pipeline: slot 0 = where the loop started (B.A)
+static Buffers slot_buffers(lpx_state* s, int k) {
+  Buffers BB = s->B;
+  if (s->pipeline == 2 && k == 1) { BB.A = s->A2; BB.b = s->b2; }
+  return BB;
+}
+
+extern "C" int lpx_shard_set_pipeline(lpx_state* s, int32_t mode) {
+  if (!s || (mode != 1 && mode != 2)) return fail(LPX_BAD_ARGUMENT, "lpx_shard_set_pipeline: mode must be 1 or 2");
+  HIP_TRY(hipSetDevice(s->device));
+  if (mode == 2 && !s->A2) {
+    const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
+    // 4 KiB skew between the two buffers: measured 346 us vs 354 us per cfg3 update with none (the read and the
+    // write stream then do not hit the same HBM channel at the same time); profiles/r01_cu_mask.log
+    const int64_t off = env_int("LPX_A2_OFFSET", 512);  // in doubles
+    HIP_TRY(hipMalloc((void**)&s->A_base[1], (size_t)(mp * s->B.ld + off) * sizeof(double)));
+    s->A2 = s->A_base[1] + off;
+    HIP_TRY(hipMalloc((void**)&s->b_base[1], (size_t)mp * sizeof(double)));
+    s->b2 = s->b_base[1];
+    HIP_TRY(hipMemset(s->A2, 0, (size_t)(mp * s->B.ld) * sizeof(double)));
+    HIP_TRY(hipMemset(s->b2, 0, (size_t)mp * sizeof(double)));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  s->pipeline = mode;
+  return 0;
+}
+
 extern "C" int lpx_shard_peek(lpx_state* s, double* d_candidate, int32_t slot, int32_t pending) {
   if (!s || !d_candidate || (slot != 0 && slot != 1)) return fail(LPX_BAD_ARGUMENT, "lpx_shard_peek: bad argument");
   HIP_TRY(hipSetDevice(s->device));
   const int prev = slot ^ 1;
   const double* prow_t = prev ? s->prow2 : s->B.prow;
+  if (s->pipeline == 2) {
+    // overlapped form: runs on the comm stream beside update(t) and reads the tableau update(t) READS (slot
+    // prev; for the prologue, without a pending pivot, the start buffer itself); only update(t-1) must be done
+    hipStream_t cs = comm_of(s);
+    if (s->upd_recorded && cs != s->stream) HIP_TRY(hipStreamWaitEvent(cs, s->ev_upd, 0));
+    const Buffers BB = slot_buffers(s, pending ? prev : slot);
+    lpxk::launch_peek(BB, s->n, s->m, s->row0, prow_t, s->B.col[prev], s->B.col[slot],
+                      pending ? &s->ring[prev] : nullptr, d_candidate, cs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   lpxk::launch_peek(s->B, s->n, s->m, s->row0, prow_t, s->B.col[prev], s->B.col[slot],
                     pending ? &s->ring[prev] : nullptr, d_candidate, s->stream);
   HIP_TRY(hipGetLastError());
@@ -583,6 +639,14 @@ extern "C" int lpx_shard_decide(lpx_state* s, const double* d_gathered, int32_t 
 extern "C" int lpx_shard_update(lpx_state* s, int32_t slot) {
   if (!s || (slot != 0 && slot != 1)) return fail(LPX_BAD_ARGUMENT, "lpx_shard_update: bad argument");
   HIP_TRY(hipSetDevice(s->device));
+  if (s->pipeline == 2) {
+    const Buffers in = slot_buffers(s, slot), out = slot_buffers(s, slot ^ 1);
+    if (int rc = launch_update_profiled(s, slot ? s->prow2 : s->B.prow, &s->ring[slot], &in, out.A, out.b)) return rc;
+    HIP_TRY(hipEventRecord(s->ev_upd, s->stream));
+    s->upd_recorded = true;
+    s->settled = false;  // the tableau may now live in either buffer until lpx_shard_poll sees the final status
+    return 0;
+  }
   return launch_update_profiled(s, slot ? s->prow2 : s->B.prow, &s->ring[slot]);
 }
 
@@ -591,11 +655,17 @@ extern "C" int lpx_shard_begin(lpx_state* s, int64_t max_pivots, int32_t track_s
   if (!s) return fail(LPX_BAD_ARGUMENT, "lpx_shard_begin: NULL state");
   HIP_TRY(hipSetDevice(s->device));
   if (s->comm_stream) HIP_TRY(hipStreamSynchronize(s->comm_stream));
+  if (!s->settled) return fail(LPX_BAD_ARGUMENT, "lpx_shard_begin: previous overlapped loop was not polled to its end");
   if (int rc = set_running(s, max_pivots, track_slot)) return rc;
+  s->upd_recorded = false;
   HIP_TRY(hipMemsetAsync(s->ring, 0, 2 * sizeof(LpxCtl), s->stream));
   launch_seed_entering(s);
   lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, -1, s->stream);
   HIP_TRY(hipGetLastError());
+  if (s->pipeline == 2) {  // the prologue peek runs on the comm stream: order it behind the seed kernels
+    HIP_TRY(hipEventRecord(s->ev_upd, s->stream));
+    s->upd_recorded = true;
+  }
   return 0;
 }
 
@@ -604,6 +674,11 @@ extern "C" int lpx_shard_poll(lpx_state* s, int64_t* pivots_done, int32_t* statu
   HIP_TRY(hipSetDevice(s->device));
   if (s->comm_stream) HIP_TRY(hipStreamSynchronize(s->comm_stream));
   if (int rc = sync_ctl_to_host(s)) return rc;
+  if (s->pipeline == 2 && !s->settled && s->h_ctl->status != lpxk::kRunning) {
+    // every performed pivot moved the tableau to the other buffer; steps after the last one were no-ops
+    if (s->h_ctl->pivots & 1) { std::swap(s->B.A, s->A2); std::swap(s->B.b, s->b2); }
+    s->settled = true;
+  }
   if (pivots_done) *pivots_done = s->h_ctl->pivots;
   if (status) *status = s->h_ctl->status;  // LPX_RUNNING (-1) while the loop is live
   return 0;

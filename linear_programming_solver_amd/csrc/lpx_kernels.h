@@ -68,8 +68,9 @@ void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& 
                          hipStream_t s);
 // prow / up: the normalised pivot row and the parameter block of the pivot to apply (B.prow / B.ctl in the
 // two-launch loop, one ring slot in the look-ahead pipeline)
+// A_out/b_out == nullptr: update (B.A, B.b) in place; otherwise read (B.A, B.b), write (A_out, b_out)
 void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometry& g, bool nontemporal,
-                   const double* prow, const LpxCtl* up, hipStream_t s);
+                   const double* prow, const LpxCtl* up, double* A_out, double* b_out, hipStream_t s);
 // shards
 void launch_propose(const Buffers& B, int n, int row0, int m_local, const Geometry& g, double* d_candidate,
                     hipStream_t s);

@@ -301,13 +301,20 @@ __global__ __launch_bounds__(1024) void k_select_pivot(const double* __restrict_
 // The thread that owns column e_next (or column 0 when the pivot being applied ends the loop) also owns
 // the b update, writes the next pivot column into col[parity] and reduces its rows' ratios into
 // partial[tile] — the next getLeaving() costs no extra pass over the tableau.
-template <int U, bool NT>
-__global__ __launch_bounds__(256) void k_update(double* __restrict__ A, int64_t ld, int m_local, int row0,
-                                                double* __restrict__ b, const double* __restrict__ prow,
+//
+// OOP = out-of-place: read the tableau from (Asrc, bsrc) and write the updated one to (A, b).  Same HBM traffic
+// (every entry read once, written once); used by the fully overlapped pipeline, where the decision of pivot
+// t+1 reads the un-updated tableau WHILE this kernel streams, which an in-place update cannot allow.
+template <int U, bool NT, bool OOP>
+__global__ __launch_bounds__(256) void k_update(double* __restrict__ A, const double* __restrict__ Asrc_, int64_t ld,
+                                                int m_local, int row0, double* __restrict__ b,
+                                                const double* __restrict__ bsrc_, const double* __restrict__ prow,
                                                 double* col0, double* col1, RatioRow* __restrict__ partial,
                                                 const LpxCtl* __restrict__ ctl, int rows_per_tile,
                                                 int nstrips) {
   if (ctl->do_update == 0) return;
+  const double* Asrc = OOP ? Asrc_ : A;
+  const double* bsrc = OOP ? bsrc_ : b;
   const int strip = blockIdx.x % nstrips;
   const int tile = blockIdx.x / nstrips;
   const int e = ctl->e_cur;
@@ -344,13 +351,15 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ A, int64_t 
     const bool has1 = i1 < r_end;
     double* row0p = A + (int64_t)i0 * ld;
     double* row1p = A + (int64_t)i1 * ld;
+    const double* src0p = Asrc + (int64_t)i0 * ld;
+    const double* src1p = Asrc + (int64_t)i1 * ld;
     const double ce0 = colcur[i0];
     const double ce1 = has1 ? colcur[i1] : 0.0;
     d2 x0[U], x1[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       if (act[k]) {
-        const d2* q0 = reinterpret_cast<const d2*>(row0p + cbase + k * 512);
+        const d2* q0 = reinterpret_cast<const d2*>(src0p + cbase + k * 512);
         x0[k] = NT ? __builtin_nontemporal_load(q0) : *q0;
       }
     }
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ A, int64_t 
 #pragma unroll
       for (int k = 0; k < U; ++k) {
         if (act[k]) {
-          const d2* q1 = reinterpret_cast<const d2*>(row1p + cbase + k * 512);
+          const d2* q1 = reinterpret_cast<const d2*>(src1p + cbase + k * 512);
           x1[k] = NT ? __builtin_nontemporal_load(q1) : *q1;
         }
       }
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ A, int64_t 
         const int i = r ? i1 : i0;
         if (r && !has1) break;
         const double ce = r ? ce1 : ce0;
-        const double bn = (i == l) ? bl : __dsub_rn(b[i], __dmul_rn(ce, bl));
+        const double bn = (i == l) ? bl : __dsub_rn(bsrc[i], __dmul_rn(ce, bl));
         b[i] = bn;
         if (en >= 0) {
           double a = 0.0;
@@ -758,21 +767,36 @@ void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& 
                      B.partial, g.ntiles, B.perm, B.ctl, forced_e, forced_l);
 }
 
-template <int U, bool NT>
+template <int U, bool NT, bool OOP>
 static void launch_update_t(const Buffers& B, int m_local, int row0, const Geometry& g, const double* prow,
-                            const LpxCtl* up, hipStream_t s) {
-  hipLaunchKernelGGL((k_update<U, NT>), dim3(g.nstrips * g.ntiles), dim3(256), 0, s, B.A, B.ld, m_local, row0,
-                     B.b, prow, B.col[0], B.col[1], B.partial, up, g.rows_per_tile, g.nstrips);
+                            const LpxCtl* up, double* A_out, double* b_out, hipStream_t s) {
+  hipLaunchKernelGGL((k_update<U, NT, OOP>), dim3(g.nstrips * g.ntiles), dim3(256), 0, s, OOP ? A_out : B.A, B.A, B.ld,
+                     m_local, row0, OOP ? b_out : B.b, B.b, prow, B.col[0], B.col[1], B.partial, up, g.rows_per_tile,
+                     g.nstrips);
 }
 
+template <int U>
+static void launch_update_u(const Buffers& B, int m_local, int row0, const Geometry& g, bool nt, const double* prow,
+                            const LpxCtl* up, double* A_out, double* b_out, hipStream_t s) {
+  const bool oop = A_out != nullptr;
+  if (oop) {
+    if (nt) launch_update_t<U, true, true>(B, m_local, row0, g, prow, up, A_out, b_out, s);
+    else launch_update_t<U, false, true>(B, m_local, row0, g, prow, up, A_out, b_out, s);
+  } else {
+    if (nt) launch_update_t<U, true, false>(B, m_local, row0, g, prow, up, A_out, b_out, s);
+    else launch_update_t<U, false, false>(B, m_local, row0, g, prow, up, A_out, b_out, s);
+  }
+}
+
+// A_out/b_out == nullptr: in place (B.A, B.b); otherwise read (B.A, B.b) and write (A_out, b_out)
 void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometry& g, bool nt, const double* prow,
-                   const LpxCtl* up, hipStream_t s) {
+                   const LpxCtl* up, double* A_out, double* b_out, hipStream_t s) {
   (void)n;
   if (g.ntiles <= 0 || g.nstrips <= 0) return;
   switch (g.U) {
-    case 1: nt ? launch_update_t<1, true>(B, m_local, row0, g, prow, up, s) : launch_update_t<1, false>(B, m_local, row0, g, prow, up, s); break;
-    case 2: nt ? launch_update_t<2, true>(B, m_local, row0, g, prow, up, s) : launch_update_t<2, false>(B, m_local, row0, g, prow, up, s); break;
-    default: nt ? launch_update_t<4, true>(B, m_local, row0, g, prow, up, s) : launch_update_t<4, false>(B, m_local, row0, g, prow, up, s); break;
+    case 1: launch_update_u<1>(B, m_local, row0, g, nt, prow, up, A_out, b_out, s); break;
+    case 2: launch_update_u<2>(B, m_local, row0, g, nt, prow, up, A_out, b_out, s); break;
+    default: launch_update_u<4>(B, m_local, row0, g, nt, prow, up, A_out, b_out, s); break;
   }
 }
 

@@ -35,7 +35,7 @@ class HipShardEngine:
     current stream."""
 
     def __init__(self, A_local, b_local, c, row0, m_global, nranks, device=0, perm=None, v=0.0, stream=None,
-                 comm_stream=None, reserve_xcds=1, pricing="reference"):
+                 comm_stream=None, reserve_xcds=1, pricing="reference", pipeline=2):
         import torch
         self.torch = torch
         L = _lib.lib()
@@ -85,6 +85,10 @@ class HipShardEngine:
         # k_commit only completes when k_update drains).
         self.comm_stream = comm_stream if comm_stream is not None else torch.cuda.Stream(device=dev, priority=-1)
         rc = self._L.lpx_shard_set_comm_stream(self._h, C.c_void_p(self.comm_stream.cuda_stream))
+        if rc:
+            raise_for_status(rc)
+        # pipeline 2 = fully overlapped (out-of-place update between two tableau buffers; 2x tableau memory)
+        rc = self._L.lpx_shard_set_pipeline(self._h, int(pipeline))
         if rc:
             raise_for_status(rc)
 

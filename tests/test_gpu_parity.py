@@ -322,10 +322,11 @@ def test_cfg2_first_pivots_follow_the_decimal_reference(lps, oracle):
 
 
 # ------------------------------------------------------------------------------------ row-block shards
-@pytest.mark.parametrize("lookahead", [False, True])
+@pytest.mark.parametrize("lookahead,pipeline", [(False, 1), (True, 1), (True, 2)])
 @pytest.mark.parametrize("nshards,shape,budget", [(2, (64, 100), -1), (4, (130, 513), 25), (8, (257, 2100), 12),
-                                                  (3, (10, 40), -1), (1, (300, 700), -1), (5, (1000, 260), 40)])
-def test_shard_kernels_on_one_gpu_match_oracle(lps, oracle, nshards, shape, budget, lookahead):
+                                                  (3, (10, 40), -1), (1, (300, 700), -1), (5, (1000, 260), 40),
+                                                  (2, (90, 700), 1), (2, (90, 700), 2), (2, (33, 64), 0)])
+def test_shard_kernels_on_one_gpu_match_oracle(lps, oracle, nshards, shape, budget, lookahead, pipeline):
     """k_propose / k_commit / k_update on row-block shards, all shards living on this one GPU and exchanging
     through LocalExchange (the multi-GPU protocol minus RCCL): bit-exact against the unsharded oracle."""
     import torch
@@ -337,10 +338,17 @@ def test_shard_kernels_on_one_gpu_match_oracle(lps, oracle, nshards, shape, budg
     for r in range(nshards):
         r0, r1 = row_block(m, nshards, r)
         engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, nshards, device=0, stream=stream,
-                                      comm_stream=comm))
+                                      comm_stream=comm, pipeline=pipeline))
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    if budget >= 0 and budget <= 2:
+        # resumed runs: odd/even pivot counts leave the tableau in either buffer of the out-of-place pipeline
+        for _ in range(3):
+            status, pivots, _ = sharded_simplex_loop(engines, LocalExchange(), max_pivots=budget, poll_every=7,
+                                                     lookahead=lookahead)
+            want = ref.simplex_loop(max_pivots=budget)
+            assert (status, pivots) == (want["status"], want["pivots"])
     status, pivots, _ = sharded_simplex_loop(engines, LocalExchange(), max_pivots=budget, poll_every=7,
                                              lookahead=lookahead)
-    ref = oracle.State(A, b, c, kind=oracle.FP64)
     want = ref.simplex_loop(max_pivots=budget)
     assert (status, pivots) == (want["status"], want["pivots"])
     wA, wb, wc, wv, wperm = ref.read()
@@ -502,7 +510,8 @@ def test_cfg4_size_properties_and_sharding_invariance(lps):
     engines = []
     for r in range(nsh):
         r0, r1 = row_block(m, nsh, r)
-        engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, nsh, device=0, stream=stream, comm_stream=comm))
+        engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, nsh, device=0, stream=stream, comm_stream=comm,
+                                      pipeline=2))
     for rep in range(3):
         status, pivots, _ = sharded_simplex_loop(engines, LocalExchange(), max_pivots=5, poll_every=4,
                                                  lookahead=(rep != 1))
