@@ -149,7 +149,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the extra cfg3 measurement of the default N=1 run")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    ap.add_argument("--poll-every", type=int, default=32)
+    ap.add_argument("--poll-every", type=int, default=64,
+                    help="sharded runs: pivots issued between two host polls of the replicated status word")
     ap.add_argument("--event-every", type=int, default=8,
                     help="bracket every N-th row-update launch of the timed region with a HIP event pair "
                          "(an event pair costs ~3 us of stream time; 1 = every launch, 0 = none)")
