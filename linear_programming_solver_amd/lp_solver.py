@@ -10,6 +10,7 @@ import numpy as np
 from . import _lib
 from .errors import raise_for_status
 from .java_compat import hashmap_key_order
+from .lp_state import LPState
 
 
 class SolveInfo:
@@ -74,3 +75,71 @@ class LPSolver:
         if rc != _lib.OPTIMAL:
             raise_for_status(rc)
         return Decimal(res.objective_text.decode())
+
+    # ---- the reference's public/package-private helpers around solve() -----------------------------------
+    @staticmethod
+    def min_in_b(b):
+        """LPSolver.minInB (LPSolver.java:375-386): first index of the strict minimum of b, -1 if empty
+        (the scan starts from 1e50, so values >= 1e50 are never selected)."""
+        mn, idx = 1e50, -1
+        for i, x in enumerate(np.asarray(b, dtype=np.float64).reshape(-1)):
+            if mn > x:
+                mn, idx = float(x), i
+        return idx
+
+    @staticmethod
+    def get_name_for_x0(coefficients):
+        """LPSolver.getNameForX0 (LPSolver.java:323-342): "x0", else "auxVar", else "auxVar<k>"."""
+        if "x0" not in coefficients:
+            return "x0"
+        if "auxVar" not in coefficients:
+            return "auxVar"
+        i = 1
+        while "auxVar%d" % i in coefficients:
+            i += 1
+        return "auxVar%d" % i
+
+    @staticmethod
+    def slack_names(coefficients, m):
+        """The slack naming of convertIntoSlackForm (LPSolver.java:255-266): x<k> for the smallest unused k."""
+        names, used, k = [], set(coefficients), 1
+        while len(names) < m:
+            nm = "x%d" % k
+            if nm not in used:
+                names.append(nm)
+                used.add(nm)
+            k += 1
+        return names
+
+    def convert_into_slack_form(self, st_form):
+        """LPSolver.convertIntoSlackForm (LPSolver.java:248-272): device-resident LPState of the slack form.
+        The reference aliases stForm's arrays and mutates its name maps; here both are copied."""
+        if st_form.has_variable_names():
+            variables = dict(st_form.variables)
+            coefficients = dict(st_form.coefficients)
+            for i, nm in enumerate(self.slack_names(coefficients, st_form.m)):
+                variables[st_form.n + i] = nm
+                coefficients[nm] = st_form.n + i
+            return LPState(st_form.A, st_form.b, st_form.c, 0.0, variables, coefficients, st_form.m, st_form.n,
+                           device=self.device)
+        return LPState(st_form.A, st_form.b, st_form.c, 0.0, None, None, st_form.m, st_form.n, device=self.device)
+
+    def convert_into_aux_lp(self, st_form):
+        """LPSolver.convertIntoAuxLP (LPSolver.java:283-321): extra column of -1, objective -x0, x0 named by
+        getNameForX0 and placed in slot n; slacks named as in convertIntoSlackForm."""
+        m, n = st_form.m, st_form.n
+        auxA = np.hstack([np.asarray(st_form.A, dtype=np.float64).reshape(m, n), -np.ones((m, 1))])
+        auxc = np.zeros(n + 1)
+        auxc[n] = -1.0
+        if st_form.has_variable_names():
+            variables, coefficients = dict(st_form.variables), dict(st_form.coefficients)
+        else:                                                  # addDefaultVariables (LPSolver.java:388-400)
+            variables = {i: "x%d" % (i + 1) for i in range(n)}
+            coefficients = {v: k for k, v in variables.items()}
+        x0 = self.get_name_for_x0(coefficients)
+        variables[n] = x0
+        coefficients[x0] = n
+        for i, nm in enumerate(self.slack_names(coefficients, m)):
+            variables[n + 1 + i] = nm
+            coefficients[nm] = n + 1 + i
+        return LPState(auxA, st_form.b, auxc, 0.0, variables, coefficients, m, n + 1, device=self.device)

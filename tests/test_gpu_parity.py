@@ -654,3 +654,27 @@ def test_dantzig_pricing_through_solve_with_phase1(lps, oracle):
         assert (got.status, got.pivots_phase1, got.pivots_phase2, got.x0_slot) == \
             (want["status"], want["pivots1"], want["pivots2"], want["x0_slot"]), t
         assert bits(np.array([got.objective]))[0] == bits(np.array([want["objective"]]))[0], t
+
+
+def test_reference_slack_and_aux_conversions(lps, reference_vectors):   # LPSolverSpec.groovy:37-74
+    g = reference_vectors["aux_lp_conversion"]
+    names = {i: "x%d" % (i + 1) for i in range(5)}
+    form = lps.LPStandardForm(g["A"], g["b"], g["c"], names, {v: k for k, v in names.items()}, 5, 5, True)
+    st = lps.LPSolver().convert_into_aux_lp(form)
+    A, b, c, v, perm = st.read()
+    assert A.tolist() == g["resA"] and c.tolist() == g["resC"] and b.tolist() == g["b"]
+    assert len(st.coefficients) == len(st.variables) == 11
+    assert "x0" in st.coefficients and st.variables[5] == "x0"
+    st.close()
+    form2 = lps.LPStandardForm(np.ones((4, 4)), np.ones(4), np.ones(4),
+                               {0: "x0", 1: "x1", 2: "x4", 3: "x6"}, {"x0": 0, "x1": 1, "x4": 2, "x6": 3}, 4, 4, True)
+    st2 = lps.LPSolver().convert_into_slack_form(form2)
+    assert len(st2.variables) == 8 and len(st2.coefficients) == 8
+    assert [st2.variables[4 + i] for i in range(4)] == ["x2", "x3", "x5", "x7"]
+    # solveAuxLP on the Spec's 4x3 aux state leaves v == 0 (LPSolverSpec.groovy:113-124)
+    h = reference_vectors["solve_aux_lp"]
+    aux = lps.LPState(h["A"], h["b"], h["c"])
+    aux.pivot(h["index_of_x0"], h["min_in_b"])
+    status, _, x0 = aux.simplex_loop(track_slot=h["min_in_b"] + 3)
+    assert status == 0 and aux.v == h["resV"] and x0 == 1          # x0 ends in slot 1 (logs/lp_solver.log:196)
+    aux.close(); st2.close()

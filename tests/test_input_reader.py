@@ -92,3 +92,24 @@ def test_get_dual_metadata_only(reference_vectors):
     from linear_programming_solver_amd.lp_standard_form import LPStandardForm
     f = LPStandardForm(np.zeros((0, 3)), [], [1, 2, 3], maximize=True)
     assert f.m == 0 and f.n == 3 and not f.has_variable_names()
+
+
+# ---- host-side helpers of LPSolver (no device work) ------------------------------------------------------
+def test_min_in_b_vectors(reference_vectors):                     # LPSolverSpec.groovy:8-21
+    from linear_programming_solver_amd.lp_solver import LPSolver
+    for case in reference_vectors["min_in_b"]["cases"]:
+        assert LPSolver.min_in_b(case["b"]) == case["answer"], case
+
+
+def test_name_for_x0():                                           # LPSolverSpec.groovy:23-35
+    from linear_programming_solver_amd.lp_solver import LPSolver
+    assert LPSolver.get_name_for_x0({"x1": 0, "x2": 1, "x3": 2}) == "x0"
+    assert LPSolver.get_name_for_x0({"x0": 0, "x1": 1}) == "auxVar"
+    assert LPSolver.get_name_for_x0({"auxVar": 0, "x0": 1, "auxVar1": 2}) == "auxVar2"
+    for coeffs in ({"x1": 0}, {"x0": 0, "x1": 1}, {"auxVar": 0, "x0": 1, "auxVar1": 2}):
+        assert LPSolver.get_name_for_x0(coeffs) not in coeffs
+
+
+def test_slack_names_skip_used_names():                           # LPSolverSpec.groovy:59-74 (x0,x1,x4,x6 taken)
+    from linear_programming_solver_amd.lp_solver import LPSolver
+    assert LPSolver.slack_names({"x0": 0, "x1": 1, "x4": 2, "x6": 3}, 4) == ["x2", "x3", "x5", "x7"]
