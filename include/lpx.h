@@ -229,6 +229,14 @@ typedef struct lpx_solve_options {
 int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, const double* b, const double* c,
               int32_t maximize, const lpx_solve_options* opts, lpx_solve_result* result);
 
+/* LPState restoreInitialLP(auxLP, initial, indexOfX0)                   LPSolver.java:200-246
+ * In place on the auxiliary-LP handle (m x (n+1), as left by phase 1): drops x0's column, rebuilds c and v by
+ * substitution in keySet() order (`order`, n original-variable indices; NULL = default-name order), renumbers
+ * the slots above x0; the handle then is the m x n LPState the reference constructs at :245.  Bug-for-bug with
+ * the reference (a nonbasic original variable is credited at its aux-LP slot; slot n returns
+ * LPX_RESTORE_INDEX_FAULT).  c0 = initial.c (already negated for `min`). */
+int lpx_restore_initial_lp(lpx_state* aux, const double* c0, int32_t n, int32_t x0_slot, const int32_t* order);
+
 /* Iteration order of a java.util.HashMap<String,Integer> filled by put("x1"), put("x2"), ... put("xn")
  * into a default-constructed map (LPSolver.addDefaultVariables, LPSolver.java:388-400): writes the
  * 0-based variable indices in keySet() order.  Host-only helper (no device work). */

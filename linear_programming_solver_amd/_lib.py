@@ -83,6 +83,7 @@ SYMBOLS = [
     ("lpx_shard_poll", C.c_int, [C.c_void_p, i64p, ip]),
     ("lpx_solve", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(SolveOptions),
                             C.POINTER(SolveResult)]),
+    ("lpx_restore_initial_lp", C.c_int, [C.c_void_p, dp, C.c_int32, C.c_int32, ip]),
     ("lpx_java_default_name_order", C.c_int, [C.c_int32, ip]),
     ("lpx_transpose", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, C.c_int64, C.c_int]),
 ]

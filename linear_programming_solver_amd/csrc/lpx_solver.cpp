@@ -120,6 +120,67 @@ struct Cleanup {
 };
 }  // namespace
 
+// restoreInitialLP(auxLP, initial, indexOfX0)                          LPSolver.java:200-246
+// In place on the auxiliary-LP state `s` (m x (n+1)): drop x0's column (:206-211), rebuild c and v by
+// substituting the basic original variables (:213-233, in keySet() order, bug-for-bug: a NONBASIC original
+// variable is credited at its aux-LP slot although c is already in post-drop numbering; slot n faults like
+// the reference's ArrayIndexOutOfBoundsException), renumber the slots above x0 (:235-244).  c0 = initial.c
+// (already negated for `min`), order = iteration order of initial.coefficients.keySet() or NULL (default names).
+extern "C" int lpx_restore_initial_lp(lpx_state* s, const double* c0, int32_t n, int32_t x0_slot,
+                                      const int32_t* order_in) {
+  if (!s || (n > 0 && !c0)) return set_error(LPX_BAD_ARGUMENT, "lpx_restore_initial_lp: NULL argument");
+  const int na = get_n(s), m = get_m(s);
+  if (na != n + 1 || x0_slot < 0 || x0_slot >= na) return set_error(LPX_BAD_ARGUMENT, "lpx_restore_initial_lp: bad shape/slot");
+  hipStream_t st = stream(s);
+  lpxk::Buffers& B = buffers(s);
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<int32_t> perm((size_t)na + m);
+  HIP_TRY(hipMemcpy(perm.data(), B.perm, perm.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  std::vector<int32_t> slot_of((size_t)n + m + 1, -1);                                // auxLP.coefficients
+  for (int sl = 0; sl < na + m; sl++)
+    if (perm[sl] >= 0 && perm[sl] <= n + m) slot_of[perm[sl]] = sl;
+  std::vector<int32_t> order(n);
+  if (order_in) order.assign(order_in, order_in + n);
+  else lpx_java_default_name_order(n, order.data());
+  std::vector<lpxk::RestoreEntry> ent;
+  ent.reserve(n);
+  for (int32_t index : order) {                                                      // :217
+    if (index < 0 || index >= n) return set_error(LPX_BAD_ARGUMENT, "lpx_restore_initial_lp: bad order entry");
+    const int cur = slot_of[index];                                                  // :220
+    if (cur < 0) return set_error(LPX_BAD_ARGUMENT, "lpx_restore_initial_lp: variable missing from perm");
+    lpxk::RestoreEntry e{};
+    e.k = c0[index];                                                                 // :219
+    if (cur >= na) { e.is_basic = 1; e.index = cur - na; }                           // :221-228
+    else {
+      if (cur >= n) return set_error(LPX_RESTORE_INDEX_FAULT, lpx_status_message(LPX_RESTORE_INDEX_FAULT));  // :231
+      e.is_basic = 0; e.index = cur;  // :231 bug-for-bug: an aux-LP slot used as a post-drop index
+    }
+    ent.push_back(e);
+  }
+  lpxk::RestoreEntry* d_ent = nullptr;
+  lpxk::launch_drop_column(B.A, B.ld, m, na, x0_slot, st);                             // :208-211
+  HIP_TRY(hipMemsetAsync(B.c, 0, (size_t)B.ld * sizeof(double), st));
+  if (!ent.empty()) {
+    HIP_TRY(hipMalloc((void**)&d_ent, ent.size() * sizeof(lpxk::RestoreEntry)));
+    hipError_t e = hipMemcpyAsync(d_ent, ent.data(), ent.size() * sizeof(lpxk::RestoreEntry), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { (void)hipFree(d_ent); return set_error(LPX_DEVICE_ERROR, hipGetErrorString(e)); }
+  }
+  reset_ctl(s, 0.0);
+  if (int rc = push(s)) { (void)hipFree(d_ent); return rc; }
+  lpxk::launch_restore_objective(B, n, d_ent, (int)ent.size(), st);                  // :213-233 (sets ctl.v)
+  std::vector<int32_t> np;                                                           // :235-244
+  np.reserve((size_t)n + m);
+  for (int sl = 0; sl < na + m; sl++)
+    if (sl != x0_slot) np.push_back(perm[sl]);
+  hipError_t e1 = hipMemcpyAsync(B.perm, np.data(), np.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+  hipError_t e2 = hipStreamSynchronize(st);
+  hipError_t e3 = hipGetLastError();
+  (void)hipFree(d_ent);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return set_error(LPX_DEVICE_ERROR, "lpx_restore_initial_lp: HIP error");
+  set_n(s, n);
+  return LPX_OPTIMAL;
+}
+
 extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, const double* b, const double* c,
                          int32_t maximize, const lpx_solve_options* opts, lpx_solve_result* res) {
   if (!res) return set_error(LPX_BAD_ARGUMENT, "lpx_solve: result is NULL");
@@ -231,46 +292,8 @@ extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, con
     }
     if (status == LPX_OPTIMAL) {
       // restoreInitialLP :200-246
-      HIP_TRY(hipMemcpy(perm.data(), B.perm, perm.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-      std::vector<int32_t> slot_of((size_t)n + m + 1, -1);                            // auxLP.coefficients
-      for (int sl = 0; sl < na + m; sl++) slot_of[perm[sl]] = sl;
-      std::vector<int32_t> order(n);
-      if (o.restore_order) order.assign(o.restore_order, o.restore_order + n);
-      else lpx_java_default_name_order(n, order.data());
-      std::vector<lpxk::RestoreEntry> ent;
-      ent.reserve(n);
-      for (int32_t index : order) {                                                  // :217
-        if (index < 0 || index >= n) { status = LPX_BAD_ARGUMENT; break; }
-        const int cur = slot_of[index];                                              // :220
-        lpxk::RestoreEntry e{};
-        e.k = c0[index];                                                             // :219
-        if (cur >= na) { e.is_basic = 1; e.index = cur - na; }                       // :221-228
-        else {
-          if (cur >= n) { status = LPX_RESTORE_INDEX_FAULT; break; }                 // AIOOBE at :231
-          e.is_basic = 0; e.index = cur;  // :231 bug-for-bug: an aux-LP slot used as a post-drop index
-        }
-        ent.push_back(e);
-      }
-      if (status == LPX_OPTIMAL) {
-        lpxk::launch_drop_column(B.A, B.ld, m, na, x0, st);                            // :208-211
-        HIP_TRY(hipMemsetAsync(B.c, 0, (size_t)B.ld * sizeof(double), st));
-        if (!ent.empty()) {
-          HIP_TRY(hipMalloc((void**)&guard.d_ent, ent.size() * sizeof(lpxk::RestoreEntry)));
-          HIP_TRY(hipMemcpyAsync(guard.d_ent, ent.data(), ent.size() * sizeof(lpxk::RestoreEntry), hipMemcpyHostToDevice, st));
-        }
-        reset_ctl(s, 0.0);
-        if (int rc2 = push(s)) { res->status = rc2; return rc2; }
-        lpxk::launch_restore_objective(B, n, guard.d_ent, (int)ent.size(), st);      // :213-233 (sets ctl.v)
-        std::vector<int32_t> np;                                                     // :235-244
-        np.reserve((size_t)n + m);
-        for (int sl = 0; sl < na + m; sl++)
-          if (sl != x0) np.push_back(perm[sl]);
-        perm.swap(np);
-        HIP_TRY(hipMemcpyAsync(B.perm, perm.data(), perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipGetLastError());
-        set_n(s, n);
-      }
+      status = lpx_restore_initial_lp(s, c0.data(), n, x0, o.restore_order);
+      if (status == LPX_DEVICE_ERROR) { res->status = status; return status; }
     }
   }
 

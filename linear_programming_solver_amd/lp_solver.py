@@ -143,3 +143,23 @@ class LPSolver:
             variables[n + 1 + i] = nm
             coefficients[nm] = n + 1 + i
         return LPState(auxA, st_form.b, auxc, 0.0, variables, coefficients, m, n + 1, device=self.device)
+
+    def restore_initial_lp(self, aux_lp, initial, index_of_x0, restore_order=None):
+        """LPSolver.restoreInitialLP (LPSolver.java:200-246), in place on the auxiliary LPState `aux_lp`, which
+        becomes the restored m x n LPState (returned).  `initial` supplies c (and, with names, the keySet()
+        iteration order of its `coefficients`)."""
+        L = _lib.lib()
+        n = initial.n
+        c0 = np.ascontiguousarray(initial.c, dtype=np.float64)
+        order = None
+        if restore_order is not None:
+            order = np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))
+        elif initial.has_variable_names() and n > 0:
+            names = [initial.variables[i] for i in range(n)]
+            order = np.array([initial.coefficients[k] for k in hashmap_key_order(names)], dtype=np.int32)
+        rc = L.lpx_restore_initial_lp(aux_lp._h, c0.ctypes.data_as(_lib.dp), n, int(index_of_x0),
+                                      None if order is None else order.ctypes.data_as(_lib.ip))
+        if rc:
+            raise_for_status(rc)
+        aux_lp.n = n                    # names stay keyed by variable id; x0's id simply no longer occurs in perm
+        return aux_lp

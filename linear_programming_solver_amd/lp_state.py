@@ -24,10 +24,12 @@ class LPState:
         A = A.reshape(self.m, self.n) if A.size == self.m * self.n else np.zeros((self.m, self.n))
         self.row0 = int(row0)
         self.m_global = int(self.m if m_global is None else m_global)
-        self._names0 = None
-        if variables is not None and coefficients is not None:
-            self._names0 = [variables.get(s) for s in range(self.n + self.m_global)]
         p = None if perm is None else np.ascontiguousarray(np.asarray(perm, dtype=np.int32))
+        self._names0 = None             # variable id -> name (the device permutes ids, the host keeps the names)
+        if variables is not None and coefficients is not None:
+            nslots = self.n + self.m_global
+            ids = list(range(nslots)) if p is None else [int(x) for x in p]
+            self._names0 = {ids[s]: variables.get(s) for s in range(nslots)}
         h = C.c_void_p()
         rc = L.lpx_state_create(self.m, self.n, A.ctypes.data_as(_lib.dp), max(self.n, 1), b.ctypes.data_as(_lib.dp),
                                 c.ctypes.data_as(_lib.dp), float(v), None if p is None else p.ctypes.data_as(_lib.ip),

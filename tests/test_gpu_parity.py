@@ -678,3 +678,31 @@ def test_reference_slack_and_aux_conversions(lps, reference_vectors):   # LPSolv
     status, _, x0 = aux.simplex_loop(track_slot=h["min_in_b"] + 3)
     assert status == 0 and aux.v == h["resV"] and x0 == 1          # x0 ends in slot 1 (logs/lp_solver.log:196)
     aux.close(); st2.close()
+
+
+def test_reference_restore_initial_lp_vector(lps, reference_vectors):     # LPSolverSpec.groovy:126-149
+    g = reference_vectors["restore_initial_lp"]
+    ident = {"x1": 0, "x2": 1, "x3": 2, "x4": 3, "x5": 4, "x6": 5, "x0": 6}   # originals, slacks, x0 = n+m
+    perm = [ident[s] for s in g["aux_names"]]
+    names = {s: nm for s, nm in enumerate(g["aux_names"])}
+    aux = lps.LPState(g["auxA"], g["auxB"], g["auxC"], 0.0, names, {v: k for k, v in names.items()}, 4, 3, perm=perm)
+    initial = lps.LPStandardForm(np.zeros((4, 2)), np.zeros(4), g["initial_c"], {0: "x1", 1: "x2"},
+                                 {"x1": 0, "x2": 1}, 4, 2, True)
+    res = lps.LPSolver().restore_initial_lp(aux, initial, g["index_of_x0"])
+    A, b, c, v, p = res.read()
+    assert A.tolist() == g["resA"] and b.tolist() == g["resB"] and c.tolist() == g["resC"] and v == g["resV"]
+    assert res.variables == {s: nm for s, nm in enumerate(g["res_names"])}
+    assert res.coefficients == {nm: s for s, nm in enumerate(g["res_names"])}
+    res.close()
+
+
+def test_restore_index_fault_is_reported(lps, decimal_goldens):
+    """A golden that triggers the reference's ArrayIndexOutOfBoundsException in restoreInitialLP."""
+    case = next(c for c in decimal_goldens["lp_cases"] if c["status"] == 6)
+    m, n = case["m"], case["n"]
+    A = np.array([float(x) for x in case["A"]]).reshape(m, n)
+    solver = lps.LPSolver()
+    with pytest.raises(IndexError):
+        solver.solve(lps.LPStandardForm(A, [float(x) for x in case["b"]], [float(x) for x in case["c"]],
+                                        maximize=case["maximize"]))
+    assert solver.last.status == 6 and solver.last.x0_slot == case["x0_slot"]
