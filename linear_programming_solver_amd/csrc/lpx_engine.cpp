@@ -73,6 +73,8 @@ struct lpx_state {
   bool nontemporal = false;
   int pricing = 0;                  // 0 = reference rule (first positive), 1 = Dantzig (opt-in extension)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
+  LpxCtl* h_snap = nullptr;         // 2 pinned snapshots for the batched loop (batch k+1 in flight while k is read)
+  hipEvent_t ev_batch[2] = {nullptr, nullptr};
   // look-ahead pipeline of the sharded loop: parameter ring, second pivot-row buffer, second stream
   LpxCtl* ring = nullptr;           // 2 device blocks
   double* prow2 = nullptr;
@@ -159,6 +161,8 @@ static void free_state(lpx_state* s) {
   if (s->ev_peek) (void)hipEventDestroy(s->ev_peek);
   if (s->ev_decide) (void)hipEventDestroy(s->ev_decide);
   if (s->h_ctl) (void)hipHostFree(s->h_ctl);
+  if (s->h_snap) (void)hipHostFree(s->h_snap);
+  for (hipEvent_t e : s->ev_batch) if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -207,6 +211,12 @@ static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, 
   hipError_t e = hipHostMalloc((void**)&s->h_ctl, sizeof(LpxCtl), hipHostMallocDefault);
   if (e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, "hipHostMalloc failed"); }
   memset(s->h_ctl, 0, sizeof(LpxCtl));
+  if (hipHostMalloc((void**)&s->h_snap, 2 * sizeof(LpxCtl), hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_batch[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&s->ev_batch[1], hipEventDisableTiming) != hipSuccess) {
+    free_state(s);
+    return fail(LPX_DEVICE_ERROR, "pinned snapshot / event allocation failed");
+  }
   e = hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, "hipStreamCreate failed"); }
   s->stream = s->own_stream;
@@ -449,11 +459,8 @@ extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivot
   int batch = (int)std::max(1.0, std::min(256.0, 1500.0 / est_us));
   batch = env_int("LPX_BATCH", batch);
 
-  hipEvent_t evs[2];
-  HIP_TRY(hipEventCreateWithFlags(&evs[0], hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&evs[1], hipEventDisableTiming));
-  LpxCtl* h2 = nullptr;  // two pinned snapshots so that batch k+1 can be in flight while k is inspected
-  HIP_TRY(hipHostMalloc((void**)&h2, 2 * sizeof(LpxCtl), hipHostMallocDefault));
+  hipEvent_t* evs = s->ev_batch;
+  LpxCtl* h2 = s->h_snap;  // two pinned snapshots so that batch k+1 can be in flight while k is inspected
 
   int64_t enqueued = 0;  // select/update pairs issued
   auto issue_batch = [&](int slot) -> int {
@@ -488,9 +495,6 @@ extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivot
   }
   hipError_t e2 = hipStreamSynchronize(s->stream);
   if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
-  (void)hipEventDestroy(evs[0]);
-  (void)hipEventDestroy(evs[1]);
-  (void)hipHostFree(h2);
   if (rc) return rc;
   if (int r2 = sync_ctl_to_host(s)) return r2;
   if (pivots_done) *pivots_done = s->h_ctl->pivots;
