@@ -204,25 +204,38 @@ __device__ __forceinline__ void finish_pivot(const double* __restrict__ raw_row,
       if (j < n && cn > kEps && first_pos == INT_MAX) first_pos = j;  // j ascends per thread
     }
   }
+  // thread 0 fetches what the finalisation needs while the block reduction runs (saves dependent round trips)
+  int32_t perm_e = 0, perm_l = 0, track = -1;
+  double v_old = 0.0;
+  if (threadIdx.x == 0) {
+    perm_e = perm[e];
+    perm_l = perm[n + l_global];
+    track = ctl->track;
+    v_old = ctl->v;
+  }
   first_pos = block_min_int(first_pos, sh_int);
   if (threadIdx.x == 0) {
-    int old = 0;
-    if (first_pos != INT_MAX) old = atomicMin(&ctl->e_min, first_pos);
-    int inc = 1;
-    asm volatile("" : "+v"(inc) : "v"(old));  // the ticket below is issued after the min has returned
-    const int ticket = atomicAdd(&ctl->ticket, inc);
-    if (ticket == (int)gridDim.x - 1) {
-      int e_min = atomicMin(&ctl->e_min, INT_MAX);  // returning atomic: the folded minimum
+    bool last = true;
+    int e_min = first_pos;
+    if (gridDim.x > 1) {  // one workgroup (small n): nothing to fold, no atomics
+      int old = 0;
+      if (first_pos != INT_MAX) old = atomicMin(&ctl->e_min, first_pos);
+      int inc = 1;
+      asm volatile("" : "+v"(inc) : "v"(old));  // the ticket below is issued after the min has returned
+      const int ticket = atomicAdd(&ctl->ticket, inc);
+      last = ticket == (int)gridDim.x - 1;
+      if (last) e_min = atomicMin(&ctl->e_min, INT_MAX);  // returning atomic: the folded minimum
+    }
+    if (last) {
       const double ce_new = -__ddiv_rn(pc, p);                                     // :172
       c[e] = ce_new;
       if (e < n && ce_new > kEps) e_min = min(e_min, e);  // possible on forced / degenerate pivots only
-      ctl->v = __dadd_rn(ctl->v, __dmul_rn(bl, pc));                               // :171
-      const int32_t t = perm[e];                                                   // exchangeIndexes :311-320
-      perm[e] = perm[n + l_global];
-      perm[n + l_global] = t;
-      if (ctl->track >= 0) {                                                       // LPSolver.java:151-155
-        if (e == ctl->track) ctl->track = l_global + n;
-        else if (l_global + n == ctl->track) ctl->track = e;
+      ctl->v = __dadd_rn(v_old, __dmul_rn(bl, pc));                                // :171
+      perm[e] = perm_l;                                                            // exchangeIndexes :311-320
+      perm[n + l_global] = perm_e;
+      if (track >= 0) {                                                            // LPSolver.java:151-155
+        if (e == track) ctl->track = l_global + n;
+        else if (l_global + n == track) ctl->track = e;
       }
       ctl->p = p;
       ctl->bl = bl;
@@ -244,8 +257,10 @@ __device__ __forceinline__ void finish_pivot(const double* __restrict__ raw_row,
         up->parity = up_parity;
         up->do_update = 1;
       }
-      atomicExch(&ctl->e_min, INT_MAX);
-      atomicExch(&ctl->ticket, 0);
+      if (gridDim.x > 1) {
+        atomicExch(&ctl->e_min, INT_MAX);
+        atomicExch(&ctl->ticket, 0);
+      }
     }
   }
 }
@@ -759,7 +774,11 @@ void launch_reduce_partials(const Buffers& B, const Geometry& g, hipStream_t s) 
 }
 
 // workgroups of the pivot-finish kernels: one column per thread up to 16 workgroups
-static int finish_blocks(int64_t ld) { return (int)std::max<int64_t>(1, std::min<int64_t>(16, (ld + 1023) / 1024)); }
+// (a single workgroup up to 4096 columns: it skips the three atomic round trips of the multi-workgroup fold)
+static int finish_blocks(int64_t ld) {
+  if (ld <= 4096) return 1;
+  return (int)std::min<int64_t>(16, (ld + 1023) / 1024);
+}
 
 void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& g, int forced_e, int forced_l,
                          hipStream_t s) {
