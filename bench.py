@@ -147,7 +147,10 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("LPX_BENCH_WORKLOAD", "cfg4"), choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cfg3", action="store_true", help="skip the extra cfg3 measurement of the default N=1 run")
+    ap.add_argument("--also-cfg3", action="store_true",
+                    help="N=1, cfg4 only: additionally measure cfg3 (BASELINE.md's single-GPU roofline config) in the "
+                         "same process and report it as an extra `cfg3` object (off by default so that a profile of "
+                         "the default command contains ONE workload)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--poll-every", type=int, default=64,
                     help="sharded runs: pivots issued between two host polls of the replicated status word")
@@ -282,7 +285,7 @@ def main():
             "host_gen_s": t_gen,
             "host_upload_s": t_up,   # hipMalloc + PCIe upload of this rank's tableau; outside the timed region
         }
-        if world == 1 and not sharded and args.workload == "cfg4" and not args.no_cfg3:
+        if world == 1 and not sharded and args.workload == "cfg4" and args.also_cfg3:
             # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
             # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)
             st.close()
