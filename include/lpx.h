@@ -112,6 +112,13 @@ int lpx_get_leaving(lpx_state* s, int32_t entering, int32_t* leaving, double* ra
  * LPX_DIVIDE_BY_ZERO and leaves the state untouched.  Single-GPU handles only. */
 int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving);
 
+/* Pivots per pass over the tableau in lpx_simplex_loop / lpx_solve ("blocked pivoting"): K pivot decisions are
+ * taken from the not-yet-updated tableau (each needs one column and one row, recovered by the pending pivots'
+ * rank-1 formulas) and then applied in ONE sweep that runs every entry through the K updates in order —
+ * bit-identical to K separate updates, 1/K of the HBM traffic per pivot.  0 = choose by size (default),
+ * 1 = off (one update pass per pivot), 2..16 = fixed. */
+int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep);
+
 /* The loop of LPSolver.simplex                                         LPSolver.java:101-107
  * while ((e = getEntering()) != -1) { l = getLeaving(e); if (l == -1) unbounded; pivot(e, l); }
  * run device-resident (no host decision per pivot) for at most max_pivots pivots (<0: unlimited).

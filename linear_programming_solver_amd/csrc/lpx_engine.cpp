@@ -72,6 +72,11 @@ struct lpx_state {
   Geometry g{};
   bool nontemporal = false;
   int pricing = 0;                  // 0 = reference rule (first positive), 1 = Dantzig (opt-in extension)
+  // blocked pivoting (K decisions from the stale tableau, then one sweep): 0 = choose by size, 1 = off
+  int block = 0;
+  int sweep_rows = 8;
+  lpxk::BlockRing R{};
+  double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
   LpxCtl* h_snap = nullptr;         // 2 pinned snapshots for the batched loop (batch k+1 in flight while k is read)
   hipEvent_t ev_batch[2] = {nullptr, nullptr};
@@ -156,6 +161,10 @@ static void free_state(lpx_state* s) {
   (void)hipFree(s->d_sum);
   (void)hipFree(s->ring);
   (void)hipFree(s->prow2);
+  (void)hipFree(s->R.prow);
+  (void)hipFree(s->R.col);
+  (void)hipFree(s->R.up);
+  (void)hipFree(s->d_cand);
   if (s->ev_upd) (void)hipEventDestroy(s->ev_upd);
 
   if (s->ev_peek) (void)hipEventDestroy(s->ev_peek);
@@ -443,12 +452,120 @@ extern "C" int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ blocked loop
+static int ensure_block_ring(lpx_state* s) {
+  if (s->R.prow) return 0;
+  const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
+  s->R.mp = mp;
+  const size_t K = lpxk::kBlockMax;
+  HIP_TRY(hipMalloc((void**)&s->R.prow, K * (size_t)s->B.ld * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s->R.col, K * (size_t)mp * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s->R.up, K * sizeof(LpxCtl)));
+  HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(s->R.prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
+  HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));
+  HIP_TRY(hipMemsetAsync(s->R.up, 0, K * sizeof(LpxCtl), s->stream));
+  HIP_TRY(hipMemsetAsync(s->d_cand, 0, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double), s->stream));
+  return 0;
+}
+
+// Pivots per sweep.  One decision (peek + pack + commit, latency-bound) costs ~18 us whatever the size; one
+// sweep costs 16*m*ld bytes at ~6 TB/s.  Blocking pays once a sweep is worth several decisions.
+static int choose_block(const lpx_state* s) {
+  int K = s->block;
+  if (K == 0) K = env_int("LPX_BLOCK", 0);
+  if (K == 0) {
+    const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
+    const double decision_us = 18.0;
+    if (sweep_us < 3.0 * decision_us) return 1;
+    K = 2;
+    while (K < lpxk::kBlockMax && K * decision_us < sweep_us) K *= 2;
+  }
+  return std::max(1, std::min(K, (int)lpxk::kBlockMax));
+}
+
+static int launch_sweep_profiled(lpx_state* s, int K) {
+  const bool sample = s->prof > 0 && (s->prof_seq++ % s->prof) == 0;
+  if (sample) {
+    if (s->ev_used + 2 > s->ev.size()) {
+      for (int k = 0; k < 512; k++) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        s->ev.push_back(e);
+      }
+    }
+    HIP_TRY(hipEventRecord(s->ev[s->ev_used], s->stream));
+  }
+  lpxk::launch_block_sweep(s->B, s->R, s->m, s->row0, K, s->sweep_rows, s->nontemporal, s->stream);
+  if (sample) {
+    HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], s->stream));
+    s->ev_used += 2;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// LPSolver.simplex's loop with K pivot decisions per pass over the tableau (bit-identical results).
+static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
+  if (int rc = ensure_block_ring(s)) return rc;
+  launch_seed_entering(s);
+  hipEvent_t* evs = s->ev_batch;
+  LpxCtl* h2 = s->h_snap;
+  int64_t decided = 0;  // decisions issued (each either pivots or reports the end)
+  auto issue_block = [&](int slot) -> int {
+    int nb = K;
+    if (max_pivots >= 0) nb = (int)std::max<int64_t>(0, std::min<int64_t>(nb, max_pivots + 1 - decided));
+    for (int k = 0; k < nb; k++) {
+      lpxk::launch_block_peek(s->B, s->R, s->n, s->m, s->row0, k, s->d_cand, s->stream);
+      lpxk::launch_block_decide(s->B, s->R, s->n, s->m_global, s->d_cand, 1, k, s->stream);
+      if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, false, s->stream);
+    }
+    decided += nb;
+    if (nb > 0) {
+      if (int rc = launch_sweep_profiled(s, nb)) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(&h2[slot], s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(evs[slot], s->stream));
+    return 0;
+  };
+  int rc = issue_block(0);
+  int cur = 0;
+  while (rc == 0) {
+    rc = issue_block(cur ^ 1);
+    if (rc) break;
+    hipError_t e = hipEventSynchronize(evs[cur]);
+    if (e != hipSuccess) { rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e)); break; }
+    if (h2[cur].status != lpxk::kRunning) break;
+    cur ^= 1;
+  }
+  hipError_t e2 = hipStreamSynchronize(s->stream);
+  if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
+  return rc;
+}
+
+extern "C" int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep) {
+  if (!s || pivots_per_sweep < 0 || pivots_per_sweep > lpxk::kBlockMax)
+    return fail(LPX_BAD_ARGUMENT, "lpx_state_set_block: 0 (auto), 1 (off) .. 16");
+  s->block = pivots_per_sweep;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ the loop
 extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivots_done, int32_t* status,
                                 int32_t* track_slot) {
   if (int rc = require_single(s, "lpx_simplex_loop")) return rc;
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = set_running(s, max_pivots, track_slot ? *track_slot : -1)) return rc;
+  const int K = choose_block(s);
+  if (K >= 2) {
+    if (int rc = blocked_loop(s, K, max_pivots)) return rc;
+    if (int r2 = sync_ctl_to_host(s)) return r2;
+    if (pivots_done) *pivots_done = s->h_ctl->pivots;
+    if (status) *status = s->h_ctl->status;
+    if (track_slot) *track_slot = s->h_ctl->track;
+    if (s->h_ctl->status == LPX_DIVIDE_BY_ZERO) return fail(LPX_DIVIDE_BY_ZERO, "pivot element is zero");
+    return 0;
+  }
   // seed: entering scan + strided column gather / partials for the first pivot
   launch_seed_entering(s);
   lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, -1, s->stream);

@@ -79,6 +79,22 @@ void launch_commit(const Buffers& B, int n, int m_global, const double* d_gather
 // look-ahead: candidate of the NEXT pivot computed from the tableau BEFORE the pending update `pend`
 void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* prow_t, const double* col_t,
                  double* col_next, const LpxCtl* pend, double* d_candidate, hipStream_t s);
+// blocked pivoting: ring of pending pivots (see lpx_kernels.hip "blocked pivoting")
+constexpr int kBlockMax = 16;
+struct BlockRing {
+  double* prow;   // kBlockMax x ld : normalised pivot row of pending pivot s
+  double* col;    // kBlockMax x mp : column e_s of the tableau just before pivot s
+  LpxCtl* up;     // kBlockMax parameter blocks (written by finish_pivot)
+  int64_t mp;
+};
+// decision number `np` of a block (np pivots pending): candidate record like k_propose's
+void launch_block_peek(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int np, double* d_candidate,
+                       hipStream_t s);
+void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_global, const double* d_gathered, int nranks,
+                         int slot, hipStream_t s);
+// apply the valid leading pending pivots (at most K) in one pass
+void launch_block_sweep(const Buffers& B, const BlockRing& R, int m_local, int row0, int K, int rows_per_tile, bool nt,
+                        hipStream_t s);
 // phase 1 / restore helpers
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
 void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);

@@ -643,6 +643,209 @@ __global__ __launch_bounds__(1024) void k_peek_pack(const double* __restrict__ A
   }
 }
 
+// ------------------------------------------------------------------------------------------------ blocked pivoting
+// K pivots per pass over the tableau ("delayed updates").  k_peek shows that the decision of the next pivot
+// needs the updated tableau only through ONE column and ONE row, both obtainable from the un-updated tableau
+// by the pending pivot's rank-1 formula.  The same holds for any number of pending pivots applied in order:
+//
+//     decision s (s = 0..K-1):  k_peek_multi  column e_s of the tableau with pivots 0..s-1 applied, from the
+//                                             stale column + s sequential corrections  -> ratio test
+//                               k_pack_multi  the winning row with pivots 0..s-1 applied, likewise
+//                               k_commit      normalise it, update c, v, perm, choose e_{s+1}  (unchanged)
+//     then ONE k_update_multi:  every tableau entry is read once, run through the K rank-1 updates in pivot
+//                               order in registers, and written once.
+//
+// Every element sees exactly the operation sequence of K separate k_update passes (one rounded product and
+// one rounded difference per pivot, same special cases for the pivot row and the entering column), so the
+// result is bit-identical — but the HBM traffic per pivot is 16*m*n/K bytes instead of 16*m*n.  Pending
+// pivots live in a ring: prow_ring[s] (ld doubles), col_ring[s] (mp doubles: column e_s BEFORE pivot s),
+// ring[s] (LpxCtl-shaped parameter block written by finish_pivot).
+constexpr int kMaxBlock = 16;
+
+__global__ __launch_bounds__(256) void k_peek_multi(const double* __restrict__ A, int64_t ld,
+                                                    const double* __restrict__ b, int m_local, int row0,
+                                                    const double* __restrict__ prow_ring,
+                                                    const double* __restrict__ col_ring, int64_t mp,
+                                                    const LpxCtl* __restrict__ ring, int np,
+                                                    double* __restrict__ col_out, RatioRow* __restrict__ partial,
+                                                    const LpxCtl* __restrict__ ctl) {
+  __shared__ RatioRow sh[4];
+  __shared__ double sh_pe[kMaxBlock], sh_p[kMaxBlock], sh_bl[kMaxBlock];
+  __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
+  if (ctl->status != kRunning) return;
+  const int en = ctl->e_next;
+  if (en < 0) return;
+  if ((int)threadIdx.x < np) {
+    const LpxCtl& q = ring[threadIdx.x];
+    sh_e[threadIdx.x] = q.e_cur;
+    sh_l[threadIdx.x] = q.l - row0;
+    sh_p[threadIdx.x] = q.p;
+    sh_bl[threadIdx.x] = q.bl;
+    sh_pe[threadIdx.x] = prow_ring[(int64_t)threadIdx.x * ld + en];
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  RatioRow best = rr_none();
+  if (i < m_local) {
+    double a = A[(int64_t)i * ld + en];
+    double bi = b[i];
+    for (int s = 0; s < np; ++s) {  // pending pivots in order: exactly what the K row updates would do
+      const double cs = col_ring[(int64_t)s * mp + i];
+      if (i == sh_l[s]) {
+        a = sh_pe[s];
+        bi = sh_bl[s];
+      } else {
+        a = (en == sh_e[s]) ? -__ddiv_rn(cs, sh_p[s]) : __dsub_rn(a, __dmul_rn(cs, sh_pe[s]));
+        bi = __dsub_rn(bi, __dmul_rn(cs, sh_bl[s]));
+      }
+    }
+    col_out[i] = a;
+    const double r = ratio_of(a, bi);
+    if (r < kInf) best = RatioRow{r, row0 + i, 0};
+  }
+  best = rr_block_min(best, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = best;
+}
+
+__global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A, int64_t ld, int n, int row0,
+                                                    const double* __restrict__ b,
+                                                    const double* __restrict__ prow_ring,
+                                                    const double* __restrict__ col_ring, int64_t mp,
+                                                    const LpxCtl* __restrict__ ring, int np,
+                                                    const RatioRow* __restrict__ partial, int nparts,
+                                                    const LpxCtl* __restrict__ ctl, double* __restrict__ cand) {
+  __shared__ RatioRow sh_rr[4];
+  __shared__ double sh_cs[kMaxBlock], sh_p[kMaxBlock], sh_bl[kMaxBlock];
+  __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
+  const int st = ctl->status;
+  RatioRow best = rr_none();
+  if (st == kRunning && ctl->e_next >= 0) {
+    for (int k = threadIdx.x; k < nparts; k += blockDim.x) best = rr_min(best, partial[k]);
+    best = rr_block_min(best, sh_rr);
+  }
+  const bool have = best.ratio < kInf;
+  const int lr = have ? best.row - row0 : -1;
+  if (have && (int)threadIdx.x < np) {
+    const LpxCtl& q = ring[threadIdx.x];
+    sh_e[threadIdx.x] = q.e_cur;
+    sh_l[threadIdx.x] = q.l - row0;
+    sh_p[threadIdx.x] = q.p;
+    sh_bl[threadIdx.x] = q.bl;
+    sh_cs[threadIdx.x] = col_ring[(int64_t)threadIdx.x * mp + lr];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    cand[0] = (st == kRunning) ? 0.0 : (double)(st + 1);
+    cand[1] = (double)ctl->e_next;
+    cand[2] = best.ratio;
+    cand[3] = have ? (double)best.row : -1.0;
+    double bn = 0.0;
+    if (have) {
+      bn = b[lr];
+      for (int s = 0; s < np; ++s) bn = (lr == sh_l[s]) ? sh_bl[s] : __dsub_rn(bn, __dmul_rn(sh_cs[s], sh_bl[s]));
+    }
+    cand[4] = bn;
+    cand[5] = cand[6] = cand[7] = 0.0;
+  }
+  if (have) {
+    const double* row = A + (int64_t)lr * ld;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+      double x = row[j];
+      for (int s = 0; s < np; ++s) {
+        const double pr = prow_ring[(int64_t)s * ld + j];
+        if (lr == sh_l[s]) x = pr;
+        else x = (j == sh_e[s]) ? -__ddiv_rn(sh_cs[s], sh_p[s]) : __dsub_rn(x, __dmul_rn(sh_cs[s], pr));
+      }
+      cand[8 + j] = x;
+    }
+  }
+}
+
+// The sweep: workgroup = rows_per_tile rows x 512 columns, thread = one 16-byte double2 per row; the thread's
+// slices of the K pending pivot rows stay in registers (2K doubles), the K multipliers of a row are scalar
+// loads.  Valid pending pivots are the leading ring slots with do_update == 1.
+template <int K, bool NT>
+__global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, int64_t ld, int m_local, int row0,
+                                                      double* __restrict__ b,
+                                                      const double* __restrict__ prow_ring,
+                                                      const double* __restrict__ col_ring, int64_t mp,
+                                                      const LpxCtl* __restrict__ ring, int kmax,
+                                                      int rows_per_tile, int nstrips) {
+  __shared__ double sh_p[K], sh_bl[K];
+  __shared__ int sh_e[K], sh_l[K];
+  __shared__ int sh_np;
+  if (threadIdx.x == 0) {
+    int cnt = 0;
+    while (cnt < K && cnt < kmax && ring[cnt].do_update != 0) ++cnt;  // slots >= kmax were not decided this block
+    sh_np = cnt;
+  }
+  if ((int)threadIdx.x < K) {
+    const LpxCtl& q = ring[threadIdx.x];
+    sh_e[threadIdx.x] = q.e_cur;
+    sh_l[threadIdx.x] = q.l - row0;
+    sh_p[threadIdx.x] = q.p;
+    sh_bl[threadIdx.x] = q.bl;
+  }
+  __syncthreads();
+  const int np = sh_np;
+  if (np == 0) return;
+  const int strip = blockIdx.x % nstrips;
+  const int tile = blockIdx.x / nstrips;
+  const int cj = strip * 512 + 2 * threadIdx.x;
+  const bool act = cj < (int)ld;
+  const int r_begin = tile * rows_per_tile;
+  const int r_end = min(m_local, r_begin + rows_per_tile);
+
+  d2 pr[K];
+  unsigned emask = 0;   // bit 2s / 2s+1: my first / second column is the entering column of pending pivot s
+  unsigned lmask = 0;   // bit s: the pivot row of pending pivot s lies in this tile (wave-uniform)
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    pr[s] = d2{0.0, 0.0};
+    if (s < np) {
+      if (act) pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj);
+      if (cj == sh_e[s]) emask |= 1u << (2 * s);
+      if (cj + 1 == sh_e[s]) emask |= 2u << (2 * s);
+      if (sh_l[s] >= r_begin && sh_l[s] < r_end) lmask |= 1u << s;
+    }
+  }
+  const bool owner = strip == 0 && threadIdx.x == 0;  // b is updated by one thread per row
+
+  for (int i = r_begin; i < r_end; ++i) {
+    double* rowp = A + (int64_t)i * ld;
+    d2 x = d2{0.0, 0.0};
+    if (act) {
+      const d2* q = reinterpret_cast<const d2*>(rowp + cj);
+      x = NT ? __builtin_nontemporal_load(q) : *q;
+    }
+    double bi = owner ? b[i] : 0.0;
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      if (s < np) {
+        const double ce = col_ring[(int64_t)s * mp + i];  // wave-uniform address: scalar load
+        if ((lmask >> s & 1u) && i == sh_l[s]) {                                   // pivot row := normalised row
+          x = pr[s];
+          if (owner) bi = sh_bl[s];
+        } else {
+          x.x = __dsub_rn(x.x, __dmul_rn(ce, pr[s].x));                            // LPState.java:162
+          x.y = __dsub_rn(x.y, __dmul_rn(ce, pr[s].y));
+          if (emask >> (2 * s) & 3u) {                                             // :157
+            const double ne = -__ddiv_rn(ce, sh_p[s]);
+            if (emask >> (2 * s) & 1u) x.x = ne;
+            if (emask >> (2 * s) & 2u) x.y = ne;
+          }
+          if (owner) bi = __dsub_rn(bi, __dmul_rn(ce, sh_bl[s]));                  // :164
+        }
+      }
+    }
+    if (act) {
+      d2* q = reinterpret_cast<d2*>(rowp + cj);
+      if (NT) __builtin_nontemporal_store(x, q); else *q = x;
+    }
+    if (owner) b[i] = bi;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ phase 1 helpers
 // convertIntoAuxLP: auxA[i][n] = -1 (LPSolver.java:293)
 __global__ void k_fill_column(double* A, int64_t ld, int m, int col, double value) {
@@ -843,6 +1046,43 @@ void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* p
                      B.partial, B.ctl, pend);
   hipLaunchKernelGGL(k_peek_pack, dim3(small_blocks(B.ld)), dim3(256), 0, s, B.A, B.ld, n, row0, B.b, prow_t, col_t,
                      B.partial, nblk, B.ctl, pend, d_candidate);
+}
+
+void launch_block_peek(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int np, double* d_candidate,
+                       hipStream_t s) {
+  const int nblk = std::max(1, (m_local + 255) / 256);
+  hipLaunchKernelGGL(k_peek_multi, dim3(nblk), dim3(256), 0, s, B.A, B.ld, B.b, m_local, row0, R.prow, R.col, R.mp, R.up,
+                     np, R.col + (int64_t)np * R.mp, B.partial, B.ctl);
+  hipLaunchKernelGGL(k_pack_multi, dim3(small_blocks(B.ld)), dim3(256), 0, s, B.A, B.ld, n, row0, B.b, R.prow, R.col,
+                     R.mp, R.up, np, B.partial, nblk, B.ctl, d_candidate);
+}
+
+void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_global, const double* d_gathered, int nranks,
+                         int slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_commit, dim3(small_blocks(B.ld)), dim3(256), 0, s, d_gathered, nranks, n, B.ld, m_global, B.c,
+                     R.prow + (int64_t)slot * B.ld, B.perm, B.ctl, R.up + slot, 0);
+}
+
+template <int K>
+static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int row0, int kmax, int rows_per_tile,
+                           bool nt, hipStream_t s) {
+  const int nstrips = (int)((B.ld + 511) / 512);
+  const int ntiles = (m_local + rows_per_tile - 1) / rows_per_tile;
+  if (nt)
+    hipLaunchKernelGGL((k_update_multi<K, true>), dim3(nstrips * ntiles), dim3(256), 0, s, B.A, B.ld, m_local, row0, B.b,
+                       R.prow, R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
+  else
+    hipLaunchKernelGGL((k_update_multi<K, false>), dim3(nstrips * ntiles), dim3(256), 0, s, B.A, B.ld, m_local, row0, B.b,
+                       R.prow, R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
+}
+
+void launch_block_sweep(const Buffers& B, const BlockRing& R, int m_local, int row0, int K, int rows_per_tile, bool nt,
+                        hipStream_t s) {
+  if (m_local <= 0) return;
+  if (K <= 2) launch_sweep_k<2>(B, R, m_local, row0, K, rows_per_tile, nt, s);
+  else if (K <= 4) launch_sweep_k<4>(B, R, m_local, row0, K, rows_per_tile, nt, s);
+  else if (K <= 8) launch_sweep_k<8>(B, R, m_local, row0, K, rows_per_tile, nt, s);
+  else launch_sweep_k<16>(B, R, m_local, row0, std::min(K, 16), rows_per_tile, nt, s);
 }
 
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {

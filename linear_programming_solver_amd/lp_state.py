@@ -11,7 +11,7 @@ from .errors import raise_for_status
 
 class LPState:
     def __init__(self, A, b, c, v=0.0, variables=None, coefficients=None, m=None, n=None, device=0,
-                 perm=None, row0=0, m_global=None, pricing="reference"):
+                 perm=None, row0=0, m_global=None, pricing="reference", block=None):
         """new LPState(A, b, c, v, variables, coefficients, m, n)  (LPState.java:101-112).
         `variables`/`coefficients` are the reference's name maps (slot -> name / name -> slot); they are
         kept on the host and permuted from the device's slot permutation on demand."""
@@ -40,6 +40,11 @@ class LPState:
         self._L = L
         if _lib.PRICING[pricing]:   # opt-in Dantzig rule: leaves the reference's pivot sequence on purpose
             rc = L.lpx_state_set_pricing(h, _lib.PRICING[pricing])
+            if rc:
+                raise_for_status(rc)
+
+        if block is not None:          # pivots per sweep of the device loop: None/0 = by size, 1 = off, 2..16
+            rc = L.lpx_state_set_block(h, int(block))
             if rc:
                 raise_for_status(rc)
 

@@ -706,3 +706,56 @@ def test_restore_index_fault_is_reported(lps, decimal_goldens):
         solver.solve(lps.LPStandardForm(A, [float(x) for x in case["b"]], [float(x) for x in case["c"]],
                                         maximize=case["maximize"]))
     assert solver.last.status == 6 and solver.last.x0_slot == case["x0_slot"]
+
+
+# ------------------------------------------------------------------------------------ blocked pivoting
+@pytest.mark.parametrize("block", [2, 3, 4, 8, 16])
+@pytest.mark.parametrize("shape", [(50, 80), (257, 300), (200, 1100), (9, 2100)])
+def test_blocked_pivoting_is_bit_identical(lps, oracle, shape, block):
+    """K pivot decisions from the stale tableau + one K-fold sweep must equal K separate updates bit for bit:
+    budgets that are not multiples of K, resumed loops, and runs to optimality."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=13 * m + n)
+    st = lps.LPState(A, b, c, block=block)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (1, block, block + 1, 3 * block - 1, 0, -1):
+        status, pivots, _ = st.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget)
+        assert (status, pivots) == (want["status"], want["pivots"]), (shape, block, budget)
+        assert_state_bits_equal(st.read(), ref.read(), "block %d budget %d of %s" % (block, budget, shape))
+    st.close()
+
+
+def test_blocked_pivoting_degenerate_unbounded_and_tracking(lps, oracle):
+    # ties everywhere
+    m, n = 70, 40
+    A = np.ones((m, n)); b = np.full(m, 3.0); c = np.arange(n, 0, -1).astype(float)
+    st = lps.LPState(A, b, c, block=4)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    status, pivots, _ = st.simplex_loop()
+    want = ref.simplex_loop()
+    assert (status, pivots) == (want["status"], want["pivots"])
+    assert_state_bits_equal(st.read(), ref.read())
+    st.close()
+    # unbounded in the middle of a block
+    st = lps.LPState([[1.0, 0.0]], [1.0], [1.0, 1.0], block=8)
+    assert st.simplex_loop()[:2] == (1, 1)
+    st.close()
+    # x0 tracking through a blocked phase-1 loop (LPSolverSpec.groovy:113-124 / logs/lp_solver.log:196)
+    A = [[1, 0, -1], [-1, 0, -1], [0, 1, -1], [0, -1, -1]]
+    aux = lps.LPState(A, [10, -2, 10, -2], [0, 0, -1], block=2)
+    aux.pivot(2, 1)
+    status, _, x0 = aux.simplex_loop(track_slot=1 + 3)
+    assert status == 0 and aux.v == 0 and x0 == 1
+    aux.close()
+
+
+def test_blocked_pivoting_with_dantzig_and_full_solve(lps, oracle):
+    A, b, c = dense_lp(300, 700, seed=99)
+    st = lps.LPState(A, b, c, pricing="dantzig", block=8)
+    ref = oracle.State(A, b, c, kind=oracle.FP64, pricing=1)
+    status, pivots, _ = st.simplex_loop()
+    want = ref.simplex_loop()
+    assert (status, pivots) == (want["status"], want["pivots"])
+    assert_state_bits_equal(st.read(), ref.read())
+    st.close()
