@@ -118,6 +118,8 @@ int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving);
  * bit-identical to K separate updates, 1/K of the HBM traffic per pivot.  0 = choose by size (default),
  * 1 = off (one update pass per pivot), 2..16 = fixed. */
 int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep);
+/* The value in effect (after the by-size choice): 1 = one update pass per pivot, K > 1 = K pivots per sweep. */
+int lpx_state_get_block(const lpx_state* s);
 
 /* The loop of LPSolver.simplex                                         LPSolver.java:101-107
  * while ((e = getEntering()) != -1) { l = getLeaving(e); if (l == -1) unbounded; pivot(e, l); }

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("lpx_state_use_masked_stream", C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     ("lpx_state_set_pricing", C.c_int, [C.c_void_p, C.c_int32]),
     ("lpx_state_set_block", C.c_int, [C.c_void_p, C.c_int32]),
+    ("lpx_state_get_block", C.c_int, [C.c_void_p]),
     ("lpx_get_entering", C.c_int, [C.c_void_p, ip]),
     ("lpx_get_leaving", C.c_int, [C.c_void_p, C.c_int32, ip, dp]),
     ("lpx_pivot", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

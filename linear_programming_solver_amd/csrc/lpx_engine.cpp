@@ -74,7 +74,7 @@ struct lpx_state {
   int pricing = 0;                  // 0 = reference rule (first positive), 1 = Dantzig (opt-in extension)
   // blocked pivoting (K decisions from the stale tableau, then one sweep): 0 = choose by size, 1 = off
   int block = 0;
-  int sweep_rows = 8;
+  int sweep_rows = 16;
   lpxk::BlockRing R{};
   double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
@@ -163,6 +163,8 @@ static void free_state(lpx_state* s) {
   (void)hipFree(s->prow2);
   (void)hipFree(s->R.prow);
   (void)hipFree(s->R.col);
+  (void)hipFree(s->R.col0);
+  (void)hipFree(s->R.row0);
   (void)hipFree(s->R.up);
   (void)hipFree(s->d_cand);
   if (s->ev_upd) (void)hipEventDestroy(s->ev_upd);
@@ -460,6 +462,10 @@ static int ensure_block_ring(lpx_state* s) {
   const size_t K = lpxk::kBlockMax;
   HIP_TRY(hipMalloc((void**)&s->R.prow, K * (size_t)s->B.ld * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.col, K * (size_t)mp * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s->R.col0, K * (size_t)mp * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s->R.row0, K * (size_t)s->B.ld * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(s->R.col0, 0, K * (size_t)mp * sizeof(double), s->stream));
+  HIP_TRY(hipMemsetAsync(s->R.row0, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.up, K * sizeof(LpxCtl)));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
@@ -496,7 +502,8 @@ static int launch_sweep_profiled(lpx_state* s, int K) {
     }
     HIP_TRY(hipEventRecord(s->ev[s->ev_used], s->stream));
   }
-  lpxk::launch_block_sweep(s->B, s->R, s->m, s->row0, K, s->sweep_rows, s->nontemporal, s->stream);
+  lpxk::launch_block_sweep(s->B, s->R, s->n, s->m, s->row0, K, env_int("LPX_SWEEP_ROWS", s->sweep_rows),
+                           s->nontemporal, s->stream);
   if (sample) {
     HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], s->stream));
     s->ev_used += 2;
@@ -542,6 +549,8 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
   return rc;
 }
+
+extern "C" int lpx_state_get_block(const lpx_state* s) { return s ? choose_block(s) : -1; }
 
 extern "C" int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep) {
   if (!s || pivots_per_sweep < 0 || pivots_per_sweep > lpxk::kBlockMax)

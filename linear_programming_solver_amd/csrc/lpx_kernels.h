@@ -84,6 +84,8 @@ constexpr int kBlockMax = 16;
 struct BlockRing {
   double* prow;   // kBlockMax x ld : normalised pivot row of pending pivot s
   double* col;    // kBlockMax x mp : column e_s of the tableau just before pivot s
+  double* col0;   // kBlockMax x mp : the same column as it stands in the stale tableau (for the fix-up)
+  double* row0;   // kBlockMax x ld : the stale pivot row l_s (for the fix-up)
   LpxCtl* up;     // kBlockMax parameter blocks (written by finish_pivot)
   int64_t mp;
 };
@@ -93,8 +95,8 @@ void launch_block_peek(const Buffers& B, const BlockRing& R, int n, int m_local,
 void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_global, const double* d_gathered, int nranks,
                          int slot, hipStream_t s);
 // apply the valid leading pending pivots (at most K) in one pass
-void launch_block_sweep(const Buffers& B, const BlockRing& R, int m_local, int row0, int K, int rows_per_tile, bool nt,
-                        hipStream_t s);
+void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
+                        bool nt, hipStream_t s);
 // phase 1 / restore helpers
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
 void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);

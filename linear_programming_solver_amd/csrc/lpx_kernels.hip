@@ -667,7 +667,8 @@ __global__ __launch_bounds__(256) void k_peek_multi(const double* __restrict__ A
                                                     const double* __restrict__ prow_ring,
                                                     const double* __restrict__ col_ring, int64_t mp,
                                                     const LpxCtl* __restrict__ ring, int np,
-                                                    double* __restrict__ col_out, RatioRow* __restrict__ partial,
+                                                    double* __restrict__ col_out, double* __restrict__ col0_out,
+                                                    RatioRow* __restrict__ partial,
                                                     const LpxCtl* __restrict__ ctl) {
   __shared__ RatioRow sh[4];
   __shared__ double sh_pe[kMaxBlock], sh_p[kMaxBlock], sh_bl[kMaxBlock];
@@ -689,6 +690,7 @@ __global__ __launch_bounds__(256) void k_peek_multi(const double* __restrict__ A
   if (i < m_local) {
     double a = A[(int64_t)i * ld + en];
     double bi = b[i];
+    col0_out[i] = a;  // the stale column, kept for k_block_fixup
     for (int s = 0; s < np; ++s) {  // pending pivots in order: exactly what the K row updates would do
       const double cs = col_ring[(int64_t)s * mp + i];
       if (i == sh_l[s]) {
@@ -713,7 +715,8 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
                                                     const double* __restrict__ col_ring, int64_t mp,
                                                     const LpxCtl* __restrict__ ring, int np,
                                                     const RatioRow* __restrict__ partial, int nparts,
-                                                    const LpxCtl* __restrict__ ctl, double* __restrict__ cand) {
+                                                    const LpxCtl* __restrict__ ctl, double* __restrict__ cand,
+                                                    double* __restrict__ row0_out) {
   __shared__ RatioRow sh_rr[4];
   __shared__ double sh_cs[kMaxBlock], sh_p[kMaxBlock], sh_bl[kMaxBlock];
   __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
@@ -751,6 +754,7 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
     const double* row = A + (int64_t)lr * ld;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
       double x = row[j];
+      row0_out[j] = x;  // the stale row, kept for k_block_fixup
       for (int s = 0; s < np; ++s) {
         const double pr = prow_ring[(int64_t)s * ld + j];
         if (lr == sh_l[s]) x = pr;
@@ -761,30 +765,28 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
   }
 }
 
-// The sweep: workgroup = rows_per_tile rows x 512 columns, thread = one 16-byte double2 per row; the thread's
-// slices of the K pending pivot rows stay in registers (2K doubles), the K multipliers of a row are scalar
-// loads.  Valid pending pivots are the leading ring slots with do_update == 1.
+// The sweep is a pure streaming kernel: x -= col_s[i] * prow_s[j] for the valid pending pivots s, in order, for
+// EVERY entry — also at the few positions where a pivot does something else (its own row becomes the normalised
+// row, its entering column becomes -(col/p)).  Those positions (K rows and K columns) are recomputed afterwards
+// by k_block_fixup from the stale values that k_peek_multi / k_pack_multi saved, with the full case analysis;
+// no entry depends on another entry, so the garbage written there in between is never read.
+// Workgroup = rows_per_tile (<= 32) rows x 512 columns, thread = one 16-byte double2 per row; the thread's
+// slices of the K pivot rows stay in registers (2K doubles), the K x rows multipliers of the tile are staged
+// once in LDS (coalesced load, broadcast reads); rows go RB at a time to keep RB loads in flight per thread.
+constexpr int kSweepMaxRows = 32;
+
 template <int K, bool NT>
-__global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, int64_t ld, int m_local, int row0,
-                                                      double* __restrict__ b,
+__global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, int64_t ld, int m_local,
                                                       const double* __restrict__ prow_ring,
                                                       const double* __restrict__ col_ring, int64_t mp,
                                                       const LpxCtl* __restrict__ ring, int kmax,
                                                       int rows_per_tile, int nstrips) {
-  __shared__ double sh_p[K], sh_bl[K];
-  __shared__ int sh_e[K], sh_l[K];
+  __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
   if (threadIdx.x == 0) {
     int cnt = 0;
     while (cnt < K && cnt < kmax && ring[cnt].do_update != 0) ++cnt;  // slots >= kmax were not decided this block
     sh_np = cnt;
-  }
-  if ((int)threadIdx.x < K) {
-    const LpxCtl& q = ring[threadIdx.x];
-    sh_e[threadIdx.x] = q.e_cur;
-    sh_l[threadIdx.x] = q.l - row0;
-    sh_p[threadIdx.x] = q.p;
-    sh_bl[threadIdx.x] = q.bl;
   }
   __syncthreads();
   const int np = sh_np;
@@ -794,55 +796,119 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
   const int cj = strip * 512 + 2 * threadIdx.x;
   const bool act = cj < (int)ld;
   const int r_begin = tile * rows_per_tile;
-  const int r_end = min(m_local, r_begin + rows_per_tile);
-
-  d2 pr[K];
-  unsigned emask = 0;   // bit 2s / 2s+1: my first / second column is the entering column of pending pivot s
-  unsigned lmask = 0;   // bit s: the pivot row of pending pivot s lies in this tile (wave-uniform)
-#pragma unroll
-  for (int s = 0; s < K; ++s) {
-    pr[s] = d2{0.0, 0.0};
-    if (s < np) {
-      if (act) pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj);
-      if (cj == sh_e[s]) emask |= 1u << (2 * s);
-      if (cj + 1 == sh_e[s]) emask |= 2u << (2 * s);
-      if (sh_l[s] >= r_begin && sh_l[s] < r_end) lmask |= 1u << s;
-    }
+  const int nrows = min(m_local, r_begin + rows_per_tile) - r_begin;
+  for (int idx = threadIdx.x; idx < K * kSweepMaxRows; idx += blockDim.x) {
+    const int sidx = idx / kSweepMaxRows, r = idx % kSweepMaxRows;
+    sh_col[sidx][r] = (sidx < np && r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;
   }
-  const bool owner = strip == 0 && threadIdx.x == 0;  // b is updated by one thread per row
-
-  for (int i = r_begin; i < r_end; ++i) {
-    double* rowp = A + (int64_t)i * ld;
-    d2 x = d2{0.0, 0.0};
-    if (act) {
-      const d2* q = reinterpret_cast<const d2*>(rowp + cj);
-      x = NT ? __builtin_nontemporal_load(q) : *q;
-    }
-    double bi = owner ? b[i] : 0.0;
+  d2 pr[K];
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-      if (s < np) {
-        const double ce = col_ring[(int64_t)s * mp + i];  // wave-uniform address: scalar load
-        if ((lmask >> s & 1u) && i == sh_l[s]) {                                   // pivot row := normalised row
-          x = pr[s];
-          if (owner) bi = sh_bl[s];
-        } else {
-          x.x = __dsub_rn(x.x, __dmul_rn(ce, pr[s].x));                            // LPState.java:162
-          x.y = __dsub_rn(x.y, __dmul_rn(ce, pr[s].y));
-          if (emask >> (2 * s) & 3u) {                                             // :157
-            const double ne = -__ddiv_rn(ce, sh_p[s]);
-            if (emask >> (2 * s) & 1u) x.x = ne;
-            if (emask >> (2 * s) & 2u) x.y = ne;
-          }
-          if (owner) bi = __dsub_rn(bi, __dmul_rn(ce, sh_bl[s]));                  // :164
-        }
+  for (int s = 0; s < K; ++s)
+    pr[s] = (s < np && act) ? *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj) : d2{0.0, 0.0};
+  __syncthreads();  // sh_col complete
+
+  constexpr int RB = 4;
+  for (int r0 = 0; r0 < nrows; r0 += RB) {
+    d2 x[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      x[r] = d2{0.0, 0.0};
+      if (r0 + r < nrows && act) {
+        const d2* q = reinterpret_cast<const d2*>(A + (int64_t)(r_begin + r0 + r) * ld + cj);
+        x[r] = NT ? __builtin_nontemporal_load(q) : *q;
       }
     }
-    if (act) {
-      d2* q = reinterpret_cast<d2*>(rowp + cj);
-      if (NT) __builtin_nontemporal_store(x, q); else *q = x;
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      if (s < np) {  // wave-uniform
+        const d2 c01 = *reinterpret_cast<const d2*>(&sh_col[s][r0]);               // LDS broadcast reads
+        const d2 c23 = *reinterpret_cast<const d2*>(&sh_col[s][r0 + 2]);
+        x[0].x = __dsub_rn(x[0].x, __dmul_rn(c01.x, pr[s].x));                     // LPState.java:162
+        x[0].y = __dsub_rn(x[0].y, __dmul_rn(c01.x, pr[s].y));
+        x[1].x = __dsub_rn(x[1].x, __dmul_rn(c01.y, pr[s].x));
+        x[1].y = __dsub_rn(x[1].y, __dmul_rn(c01.y, pr[s].y));
+        x[2].x = __dsub_rn(x[2].x, __dmul_rn(c23.x, pr[s].x));
+        x[2].y = __dsub_rn(x[2].y, __dmul_rn(c23.x, pr[s].y));
+        x[3].x = __dsub_rn(x[3].x, __dmul_rn(c23.y, pr[s].x));
+        x[3].y = __dsub_rn(x[3].y, __dmul_rn(c23.y, pr[s].y));
+      }
     }
-    if (owner) b[i] = bi;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      if (r0 + r < nrows && act) {
+        d2* q = reinterpret_cast<d2*>(A + (int64_t)(r_begin + r0 + r) * ld + cj);
+        if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
+      }
+    }
+  }
+}
+
+// One pivot applied to one value with the reference's full case analysis (LPState.java:139-164): the value at
+// row i, column j before pivot r -> after pivot r.
+__device__ __forceinline__ double apply_pivot(double v, int i, int j, int l_r, int e_r, double p_r, double ce,
+                                              double pr_j) {
+  if (i == l_r) return pr_j;                       // pivot row := normalised row (pr_j = 1/p at j == e_r)
+  if (j == e_r) return -__ddiv_rn(ce, p_r);        // :157
+  return __dsub_rn(v, __dmul_rn(ce, pr_j));        // :162
+}
+
+// After the sweep: recompute the entering columns (job 0), the pivot rows (job 1) and b (job 2) of the valid
+// pending pivots from the saved stale values.  grid = (ceil(max(m, ld)/256), K, 3).
+__global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int64_t ld, int n, int m_local, int row0,
+                                                     double* __restrict__ b, const double* __restrict__ prow_ring,
+                                                     const double* __restrict__ col_ring,
+                                                     const double* __restrict__ col0_ring,
+                                                     const double* __restrict__ row0_ring, int64_t mp,
+                                                     const LpxCtl* __restrict__ ring, int kmax) {
+  __shared__ double sh_p[kMaxBlock], sh_bl[kMaxBlock], sh_x[kMaxBlock];
+  __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
+  __shared__ int sh_np;
+  const int s = blockIdx.y, job = blockIdx.z;
+  if (threadIdx.x == 0) {
+    int cnt = 0;
+    while (cnt < kMaxBlock && cnt < kmax && ring[cnt].do_update != 0) ++cnt;
+    sh_np = cnt;
+  }
+  __syncthreads();
+  const int np = sh_np;
+  if (s >= np || (job == 2 && s != 0)) return;
+  if ((int)threadIdx.x < np) {
+    const LpxCtl& q = ring[threadIdx.x];
+    sh_e[threadIdx.x] = q.e_cur;
+    sh_l[threadIdx.x] = q.l - row0;
+    sh_p[threadIdx.x] = q.p;
+    sh_bl[threadIdx.x] = q.bl;
+  }
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (job == 0) {  // entering column of pending pivot s, all local rows
+    const int j = sh_e[s];
+    if ((int)threadIdx.x < np) sh_x[threadIdx.x] = prow_ring[(int64_t)threadIdx.x * ld + j];
+    __syncthreads();
+    if (t < m_local) {
+      double v = col0_ring[(int64_t)s * mp + t];
+      for (int r = 0; r < np; ++r)
+        v = apply_pivot(v, t, j, sh_l[r], sh_e[r], sh_p[r], col_ring[(int64_t)r * mp + t], sh_x[r]);
+      A[(int64_t)t * ld + j] = v;
+    }
+  } else if (job == 1) {  // pivot row of pending pivot s (if it lives on this shard), all columns
+    const int i = sh_l[s];
+    if (i < 0 || i >= m_local) return;
+    if ((int)threadIdx.x < np) sh_x[threadIdx.x] = col_ring[(int64_t)threadIdx.x * mp + i];
+    __syncthreads();
+    if (t < (int)ld) {
+      double v = t < n ? row0_ring[(int64_t)s * ld + t] : 0.0;
+      for (int r = 0; r < np; ++r)
+        v = apply_pivot(v, i, t, sh_l[r], sh_e[r], sh_p[r], sh_x[r], prow_ring[(int64_t)r * ld + t]);
+      A[(int64_t)i * ld + t] = v;
+    }
+  } else {  // b of every local row (LPState.java:164 / :146)
+    if (t < m_local) {
+      double bi = b[t];
+      for (int r = 0; r < np; ++r)
+        bi = (t == sh_l[r]) ? sh_bl[r] : __dsub_rn(bi, __dmul_rn(col_ring[(int64_t)r * mp + t], sh_bl[r]));
+      b[t] = bi;
+    }
   }
 }
 
@@ -1052,9 +1118,9 @@ void launch_block_peek(const Buffers& B, const BlockRing& R, int n, int m_local,
                        hipStream_t s) {
   const int nblk = std::max(1, (m_local + 255) / 256);
   hipLaunchKernelGGL(k_peek_multi, dim3(nblk), dim3(256), 0, s, B.A, B.ld, B.b, m_local, row0, R.prow, R.col, R.mp, R.up,
-                     np, R.col + (int64_t)np * R.mp, B.partial, B.ctl);
+                     np, R.col + (int64_t)np * R.mp, R.col0 + (int64_t)np * R.mp, B.partial, B.ctl);
   hipLaunchKernelGGL(k_pack_multi, dim3(small_blocks(B.ld)), dim3(256), 0, s, B.A, B.ld, n, row0, B.b, R.prow, R.col,
-                     R.mp, R.up, np, B.partial, nblk, B.ctl, d_candidate);
+                     R.mp, R.up, np, B.partial, nblk, B.ctl, d_candidate, R.row0 + (int64_t)np * B.ld);
 }
 
 void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_global, const double* d_gathered, int nranks,
@@ -1064,25 +1130,30 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 }
 
 template <int K>
-static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int row0, int kmax, int rows_per_tile,
-                           bool nt, hipStream_t s) {
+static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_tile, bool nt,
+                           hipStream_t s) {
   const int nstrips = (int)((B.ld + 511) / 512);
   const int ntiles = (m_local + rows_per_tile - 1) / rows_per_tile;
   if (nt)
-    hipLaunchKernelGGL((k_update_multi<K, true>), dim3(nstrips * ntiles), dim3(256), 0, s, B.A, B.ld, m_local, row0, B.b,
-                       R.prow, R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
+    hipLaunchKernelGGL((k_update_multi<K, true>), dim3(nstrips * ntiles), dim3(256), 0, s, B.A, B.ld, m_local, R.prow,
+                       R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
   else
-    hipLaunchKernelGGL((k_update_multi<K, false>), dim3(nstrips * ntiles), dim3(256), 0, s, B.A, B.ld, m_local, row0, B.b,
-                       R.prow, R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
+    hipLaunchKernelGGL((k_update_multi<K, false>), dim3(nstrips * ntiles), dim3(256), 0, s, B.A, B.ld, m_local, R.prow,
+                       R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
 }
 
-void launch_block_sweep(const Buffers& B, const BlockRing& R, int m_local, int row0, int K, int rows_per_tile, bool nt,
-                        hipStream_t s) {
+void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
+                        bool nt, hipStream_t s) {
   if (m_local <= 0) return;
-  if (K <= 2) launch_sweep_k<2>(B, R, m_local, row0, K, rows_per_tile, nt, s);
-  else if (K <= 4) launch_sweep_k<4>(B, R, m_local, row0, K, rows_per_tile, nt, s);
-  else if (K <= 8) launch_sweep_k<8>(B, R, m_local, row0, K, rows_per_tile, nt, s);
-  else launch_sweep_k<16>(B, R, m_local, row0, std::min(K, 16), rows_per_tile, nt, s);
+  rows_per_tile = std::max(4, std::min(rows_per_tile, kSweepMaxRows)) & ~3;  // rows go four at a time
+  K = std::min(K, (int)kMaxBlock);
+  if (K <= 2) launch_sweep_k<2>(B, R, m_local, K, rows_per_tile, nt, s);
+  else if (K <= 4) launch_sweep_k<4>(B, R, m_local, K, rows_per_tile, nt, s);
+  else if (K <= 8) launch_sweep_k<8>(B, R, m_local, K, rows_per_tile, nt, s);
+  else launch_sweep_k<16>(B, R, m_local, K, rows_per_tile, nt, s);
+  const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
+  hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
+                     R.col0, R.row0, R.mp, R.up, K);
 }
 
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {

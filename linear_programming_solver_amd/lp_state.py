@@ -143,6 +143,10 @@ class LPState:
         v = self.variables
         return None if v is None else {name: s for s, name in v.items()}
 
+    def block(self):
+        """Pivots per sweep in effect for the device loop (1 = one update pass per pivot)."""
+        return int(self._L.lpx_state_get_block(self._h))
+
     def checksum(self):
         out = (C.c_uint64 * 3)()
         rc = self._L.lpx_state_checksum(self._h, out)
