@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("LPX_BENCH_PIPELINE", "2")), choices=[1, 2],
                     help="sharded look-ahead form: 1 = in-place update, peek before it; 2 = out-of-place update "
                          "between two tableau buffers, peek + exchange + decision all beside the running update")
+    ap.add_argument("--block", type=int, default=int(os.environ.get("LPX_BENCH_BLOCK", "-1")),
+                    help="sharded runs: pivots per sweep (blocked pivoting); -1 = 16 when one rank's sweep is worth "
+                         "several decisions, else 1 (then the look-ahead pipeline is used); 1 = off")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-block shard engine + the torch.distributed collective even at N=1")
     args = ap.parse_args()
@@ -232,17 +235,20 @@ def main():
         objective = st.v
         eng = st
     else:
-        eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank, pipeline=args.pipeline)
+        block = args.block
+        if block < 0:   # one decision incl. the exchange ~60 us; a rank's sweep 16*m_local*n bytes at ~6 TB/s
+            block = 16 if 16.0 * (r1 - r0) * n / 6.0e6 > 3 * 60.0 else 1
+        eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank, pipeline=args.pipeline if block == 1 else 1)
         t_up = time.perf_counter() - t_up
         ex = DistExchange()
         status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=W, poll_every=args.poll_every,
-                                              lookahead=not args.no_lookahead)
+                                              lookahead=not args.no_lookahead, block=block)
         assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
-        eng.profile_enable(args.event_every)
+        eng.profile_enable(args.event_every if block == 1 else (1 if args.event_every > 0 else 0))
         barrier()
         t0 = time.perf_counter()
         status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=K, poll_every=args.poll_every,
-                                              lookahead=not args.no_lookahead)
+                                              lookahead=not args.no_lookahead, block=block)
         barrier()
         elapsed = time.perf_counter() - t0
         launches, kernel_ms = eng.profile_read()
@@ -252,7 +258,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
-    if not sharded and block > 1:
+    if block > 1:
         # blocked pivoting: ceil((K+1)/block) sweeps (the last decision of a budgeted run only reports the end)
         expect = 0 if args.event_every <= 0 else (K + 1 + block - 1) // block
         sampled_pivots = K                      # every sweep is timed: together they applied all K pivots
@@ -285,9 +291,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: dense random LP m=%d n=%d fp64 (A~U(0,1), b=(n/4)U(1,2), c~U(0,1), max), "
                                    "first-positive entering rule, %d pivots after %d warm-up" % (args.workload, m, n, K, W),
-                       "m": m, "n": n, "seed": args.seed,
-                       "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot%s" % (
-                           world, "" if args.no_lookahead else ", look-ahead pipeline %d" % args.pipeline)},
+                       "m": m, "n": n, "seed": args.seed, "pivots_per_sweep": block,
+                       "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot, %s" % (
+                           world, ("blocked x%d" % block) if block > 1 else
+                           ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_update" if block == 1 else "k_update_multi", "avg_kernel_ms": avg_ms,

@@ -192,6 +192,13 @@ int lpx_shard_set_pipeline(lpx_state* s, int32_t mode);
 int lpx_shard_peek(lpx_state* s, double* d_candidate, int32_t slot, int32_t pending);
 int lpx_shard_decide(lpx_state* s, const double* d_gathered, int32_t nranks, int32_t slot);
 int lpx_shard_update(lpx_state* s, int32_t slot);
+/* Row-block shards, blocked form (see lpx_state_set_block): per block of K <= 16 decisions the host issues, for
+ * slot = 0..K-1,   lpx_shard_block_peek(s, cand, slot) -> all-gather of cand -> lpx_shard_block_decide(s, gathered,
+ * G, slot),   then ONE lpx_shard_block_sweep(s, K) that applies the (valid) decided pivots to the shard's rows in
+ * a single pass.  After lpx_shard_begin; everything on the handle's main stream; no host sync. */
+int lpx_shard_block_peek(lpx_state* s, double* d_candidate, int32_t slot);
+int lpx_shard_block_decide(lpx_state* s, const double* d_gathered, int32_t nranks, int32_t slot);
+int lpx_shard_block_sweep(lpx_state* s, int32_t nslots);
 /* Host poll of the replicated loop state: pivots done so far and LPX_RUNNING (-1, loop still live) or
  * LPX_OPTIMAL / LPX_UNBOUNDED / LPX_PIVOT_LIMIT.  Synchronises the stream. */
 #define LPX_RUNNING (-1)

@@ -82,6 +82,9 @@ SYMBOLS = [
     ("lpx_shard_peek", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("lpx_shard_decide", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("lpx_shard_update", C.c_int, [C.c_void_p, C.c_int32]),
+    ("lpx_shard_block_peek", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    ("lpx_shard_block_decide", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    ("lpx_shard_block_sweep", C.c_int, [C.c_void_p, C.c_int32]),
     ("lpx_shard_poll", C.c_int, [C.c_void_p, i64p, ip]),
     ("lpx_solve", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(SolveOptions),
                             C.POINTER(SolveResult)]),

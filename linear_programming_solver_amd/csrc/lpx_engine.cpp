@@ -552,6 +552,36 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
 
 extern "C" int lpx_state_get_block(const lpx_state* s) { return s ? choose_block(s) : -1; }
 
+// ---- blocked pivoting on row-block shards: the host exchanges the candidate of every decision ---------------
+extern "C" int lpx_shard_block_peek(lpx_state* s, double* d_candidate, int32_t slot) {
+  if (!s || !d_candidate || slot < 0 || slot >= lpxk::kBlockMax)
+    return fail(LPX_BAD_ARGUMENT, "lpx_shard_block_peek: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = ensure_block_ring(s)) return rc;
+  lpxk::launch_block_peek(s->B, s->R, s->n, s->m, s->row0, slot, d_candidate, s->stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int lpx_shard_block_decide(lpx_state* s, const double* d_gathered, int32_t nranks, int32_t slot) {
+  if (!s || !d_gathered || nranks < 1 || slot < 0 || slot >= lpxk::kBlockMax)
+    return fail(LPX_BAD_ARGUMENT, "lpx_shard_block_decide: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (int rc = ensure_block_ring(s)) return rc;
+  lpxk::launch_block_decide(s->B, s->R, s->n, s->m_global, d_gathered, nranks, slot, s->stream);
+  if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, false, s->stream);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int lpx_shard_block_sweep(lpx_state* s, int32_t nslots) {
+  if (!s || nslots < 0 || nslots > lpxk::kBlockMax) return fail(LPX_BAD_ARGUMENT, "lpx_shard_block_sweep: bad argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (nslots == 0) return 0;
+  if (int rc = ensure_block_ring(s)) return rc;
+  return launch_sweep_profiled(s, nslots);
+}
+
 extern "C" int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep) {
   if (!s || pivots_per_sweep < 0 || pivots_per_sweep > lpxk::kBlockMax)
     return fail(LPX_BAD_ARGUMENT, "lpx_state_set_block: 0 (auto), 1 (off) .. 16");

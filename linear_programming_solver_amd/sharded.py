@@ -135,6 +135,22 @@ class HipShardEngine:
         if rc:
             raise_for_status(rc)
 
+    # ---- blocked form: K decisions from the stale tableau, then one K-fold sweep
+    def block_peek(self, slot):
+        rc = self._L.lpx_shard_block_peek(self._h, C.c_void_p(self.cand.data_ptr()), int(slot))
+        if rc:
+            raise_for_status(rc)
+
+    def block_decide(self, slot):
+        rc = self._L.lpx_shard_block_decide(self._h, C.c_void_p(self.gathered.data_ptr()), self.nranks, int(slot))
+        if rc:
+            raise_for_status(rc)
+
+    def block_sweep(self, nslots):
+        rc = self._L.lpx_shard_block_sweep(self._h, int(nslots))
+        if rc:
+            raise_for_status(rc)
+
     def poll(self):
         piv, st = C.c_int64(), C.c_int32()
         rc = self._L.lpx_shard_poll(self._h, C.byref(piv), C.byref(st))
@@ -246,9 +262,45 @@ def sharded_simplex_loop_lookahead(engines, exchange, max_pivots=-1, track_slot=
             raise RuntimeError("pivot budget exhausted but loop still running")
 
 
-def sharded_simplex_loop(engines, exchange, max_pivots=-1, track_slot=-1, poll_every=16, lookahead=False):
+def sharded_simplex_loop_blocked(engines, exchange, block, max_pivots=-1, track_slot=-1, poll_blocks=4):
+    """Blocked pivoting over shards: per block, `block` decisions (each: local candidate from the STALE shard via
+    the pending pivots' rank-1 corrections -> all-gather -> identical decision on every rank), then one sweep that
+    applies all of them in a single pass over the shard (1/block of the HBM traffic per pivot, bit-identical).
+    Returns (status, pivots, decisions_issued)."""
+    for e in engines:
+        e.begin(max_pivots, track_slot)
+    decided = 0
+    while True:
+        for _ in range(poll_blocks):
+            nb = block
+            if max_pivots >= 0:
+                nb = max(0, min(nb, max_pivots + 1 - decided))   # the last decision of a budgeted run is the probe
+            for k in range(nb):
+                for e in engines:
+                    e.block_peek(k)
+                exchange.all_gather(engines)
+                for e in engines:
+                    e.block_decide(k)
+            for e in engines:
+                e.block_sweep(nb)
+            decided += nb
+            if nb == 0:
+                break
+        polled = [e.poll() for e in engines]
+        pivots, status = polled[0]
+        assert all(p == polled[0] for p in polled), "replicated loop state diverged: %r" % (polled,)
+        if status != RUNNING:
+            return status, pivots, decided
+        if max_pivots >= 0 and decided >= max_pivots + 1:
+            raise RuntimeError("pivot budget exhausted but loop still running")
+
+
+def sharded_simplex_loop(engines, exchange, max_pivots=-1, track_slot=-1, poll_every=16, lookahead=False, block=1):
     """LPSolver.simplex's loop (LPSolver.java:101-107) over row-block shards.  `engines`: the shard engines
     living in this process (one per rank in production).  Returns (status, pivots, iterations_issued)."""
+    if block > 1:
+        return sharded_simplex_loop_blocked(engines, exchange, block, max_pivots, track_slot,
+                                            poll_blocks=max(1, poll_every // block))
     if lookahead:
         return sharded_simplex_loop_lookahead(engines, exchange, max_pivots, track_slot, poll_every)
     for e in engines:

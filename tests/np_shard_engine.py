@@ -125,6 +125,17 @@ class NumpyShardEngine:
                 self.A[li] = prow
                 self.b[li] = bl
 
+    # ---- blocked form: a sequential engine simply applies the pending pivot before looking again
+    def block_peek(self, slot):
+        self._apply_pending()
+        self.propose()
+
+    def block_decide(self, slot):
+        self.decide(slot)
+
+    def block_sweep(self, nslots):
+        self._apply_pending()
+
     def poll(self):
         return self.pivots, self.status
 

@@ -759,3 +759,34 @@ def test_blocked_pivoting_with_dantzig_and_full_solve(lps, oracle):
     assert (status, pivots) == (want["status"], want["pivots"])
     assert_state_bits_equal(st.read(), ref.read())
     st.close()
+
+
+@pytest.mark.parametrize("block", [2, 5, 16])
+@pytest.mark.parametrize("nshards,shape,budget", [(2, (64, 100), -1), (4, (130, 513), 25), (8, (257, 2100), 12),
+                                                  (3, (10, 40), -1), (5, (1000, 260), 40)])
+def test_blocked_pivoting_on_shards_matches_oracle(lps, oracle, nshards, shape, budget, block):
+    """Blocked pivoting over row-block shards (all shards on this GPU, LocalExchange): every decision's candidate
+    comes from the stale shard + corrections, the winner's stale row is saved on its owner for the fix-up."""
+    import torch
+    from linear_programming_solver_amd.sharded import HipShardEngine, LocalExchange, row_block, sharded_simplex_loop
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=m + n)
+    stream = torch.cuda.Stream()
+    engines = []
+    for r in range(nshards):
+        r0, r1 = row_block(m, nshards, r)
+        engines.append(HipShardEngine(A[r0:r1], b[r0:r1], c, r0, m, nshards, device=0, stream=stream,
+                                      comm_stream=stream, pipeline=1))
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for _ in range(2):
+        status, pivots, _ = sharded_simplex_loop(engines, LocalExchange(), max_pivots=budget, poll_every=32, block=block)
+        want = ref.simplex_loop(max_pivots=budget)
+        assert (status, pivots) == (want["status"], want["pivots"])
+    wA, wb, wc, wv, wperm = ref.read()
+    for e in engines:
+        gA, gb, gc, gv, gperm = e.read()
+        r0 = e.row0
+        assert np.array_equal(bits(gA), bits(wA[r0:r0 + e.m_local]))
+        assert np.array_equal(bits(gb), bits(wb[r0:r0 + e.m_local]))
+        assert np.array_equal(bits(gc), bits(wc)) and gv == wv and list(gperm) == list(wperm)
+        e.close()

@@ -29,7 +29,7 @@ def _lp(m, n, seed):
     return rng.random((m, n)), (n / 4.0) * (1.0 + rng.random(m)), rng.random(n)
 
 
-def _worker(rank, world, port, m, n, seed, budget, outdir, lookahead=False):
+def _worker(rank, world, port, m, n, seed, budget, outdir, lookahead=False, block=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, m, n, seed, budget, outdir, lookahead=False):
         r0, r1 = row_block(m, world, rank)
         eng = NumpyShardEngine(A[r0:r1], b[r0:r1], c, r0, m, world)
         status, pivots, _ = sharded_simplex_loop([eng], DistExchange(), max_pivots=budget, poll_every=5,
-                                                 lookahead=lookahead)
+                                                 lookahead=lookahead, block=block)
         Al, bl, cl, v, perm = eng.read()
         np.savez(os.path.join(outdir, "rank%d.npz" % rank), A=Al, b=bl, c=cl, v=v, perm=perm, status=status,
                  pivots=pivots, r0=r0, r1=r1)
@@ -48,14 +48,14 @@ def _worker(rank, world, port, m, n, seed, budget, outdir, lookahead=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape,budget,lookahead", [(2, (37, 50), -1, False), (2, (64, 40), 7, False),
-                                                        (3, (50, 33), -1, False), (2, (41, 30), -1, True),
-                                                        (2, (64, 40), 7, True)])
-def test_gloo_sharded_loop_matches_oracle(tmp_path, oracle, world, shape, budget, lookahead):
+@pytest.mark.parametrize("world,shape,budget,lookahead,block", [
+    (2, (37, 50), -1, False, 1), (2, (64, 40), 7, False, 1), (3, (50, 33), -1, False, 1), (2, (41, 30), -1, True, 1),
+    (2, (64, 40), 7, True, 1), (2, (41, 30), -1, False, 4), (2, (64, 40), 7, False, 3)])
+def test_gloo_sharded_loop_matches_oracle(tmp_path, oracle, world, shape, budget, lookahead, block):
     m, n = shape
     seed = 100 + m
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, m, n, seed, budget, str(tmp_path), lookahead), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, m, n, seed, budget, str(tmp_path), lookahead, block), nprocs=world, join=True)
     A, b, c = _lp(m, n, seed)
     ref = oracle.State(A, b, c, kind=oracle.FP64)
     want = ref.simplex_loop(max_pivots=budget)
