@@ -475,17 +475,17 @@ static int ensure_block_ring(lpx_state* s) {
   return 0;
 }
 
-// Pivots per sweep.  One decision (peek + pack + commit, latency-bound) costs ~18 us whatever the size; one
-// sweep costs 16*m*ld bytes at ~6 TB/s.  Blocking pays once a sweep is worth several decisions.
+// Pivots per sweep.  Measured on MI355X: one decision (peek + pack + commit, three latency-bound launches) costs
+// ~14 us + ~0.4 us per pending pivot whatever the size; a sweep moves the tableau once at ~5.6 TB/s; the
+// one-pass form costs one pass at ~6.3 TB/s + ~9 us per pivot.  Per pivot: blocked(K) ~ 14 + 0.2 K + sweep/K.
 static int choose_block(const lpx_state* s) {
   int K = s->block;
   if (K == 0) K = env_int("LPX_BLOCK", 0);
   if (K == 0) {
     const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
-    const double decision_us = 18.0;
-    if (sweep_us < 3.0 * decision_us) return 1;
-    K = 2;
-    while (K < lpxk::kBlockMax && K * decision_us < sweep_us) K *= 2;
+    if (sweep_us < 15.0) K = 1;        // cache-resident tableaux: the two-launch loop wins
+    else if (sweep_us < 50.0) K = 8;
+    else K = 16;
   }
   return std::max(1, std::min(K, (int)lpxk::kBlockMax));
 }

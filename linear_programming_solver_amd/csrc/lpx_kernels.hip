@@ -807,7 +807,7 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
     pr[s] = (s < np && act) ? *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj) : d2{0.0, 0.0};
   __syncthreads();  // sh_col complete
 
-  constexpr int RB = 4;
+  constexpr int RB = (K <= 8) ? 8 : 4;   // rows in flight per thread (register budget: 2K doubles of pivot rows)
   for (int r0 = 0; r0 < nrows; r0 += RB) {
     d2 x[RB];
 #pragma unroll
@@ -821,16 +821,14 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
 #pragma unroll
     for (int s = 0; s < K; ++s) {
       if (s < np) {  // wave-uniform
-        const d2 c01 = *reinterpret_cast<const d2*>(&sh_col[s][r0]);               // LDS broadcast reads
-        const d2 c23 = *reinterpret_cast<const d2*>(&sh_col[s][r0 + 2]);
-        x[0].x = __dsub_rn(x[0].x, __dmul_rn(c01.x, pr[s].x));                     // LPState.java:162
-        x[0].y = __dsub_rn(x[0].y, __dmul_rn(c01.x, pr[s].y));
-        x[1].x = __dsub_rn(x[1].x, __dmul_rn(c01.y, pr[s].x));
-        x[1].y = __dsub_rn(x[1].y, __dmul_rn(c01.y, pr[s].y));
-        x[2].x = __dsub_rn(x[2].x, __dmul_rn(c23.x, pr[s].x));
-        x[2].y = __dsub_rn(x[2].y, __dmul_rn(c23.x, pr[s].y));
-        x[3].x = __dsub_rn(x[3].x, __dmul_rn(c23.y, pr[s].x));
-        x[3].y = __dsub_rn(x[3].y, __dmul_rn(c23.y, pr[s].y));
+#pragma unroll
+        for (int r = 0; r < RB; r += 2) {
+          const d2 cc = *reinterpret_cast<const d2*>(&sh_col[s][(r0 + r) & (kSweepMaxRows - 1)]);  // LDS broadcast
+          x[r].x = __dsub_rn(x[r].x, __dmul_rn(cc.x, pr[s].x));                    // LPState.java:162
+          x[r].y = __dsub_rn(x[r].y, __dmul_rn(cc.x, pr[s].y));
+          x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(cc.y, pr[s].x));
+          x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(cc.y, pr[s].y));
+        }
       }
     }
 #pragma unroll
@@ -1145,7 +1143,7 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
 void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
                         bool nt, hipStream_t s) {
   if (m_local <= 0) return;
-  rows_per_tile = std::max(4, std::min(rows_per_tile, kSweepMaxRows)) & ~3;  // rows go four at a time
+  rows_per_tile = std::max(8, std::min(rows_per_tile, kSweepMaxRows)) & ~7;  // rows go four or eight at a time
   K = std::min(K, (int)kMaxBlock);
   if (K <= 2) launch_sweep_k<2>(B, R, m_local, K, rows_per_tile, nt, s);
   else if (K <= 4) launch_sweep_k<4>(B, R, m_local, K, rows_per_tile, nt, s);
