@@ -116,7 +116,7 @@ int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving);
  * taken from the not-yet-updated tableau (each needs one column and one row, recovered by the pending pivots'
  * rank-1 formulas) and then applied in ONE sweep that runs every entry through the K updates in order —
  * bit-identical to K separate updates, 1/K of the HBM traffic per pivot.  0 = choose by size (default),
- * 1 = off (one update pass per pivot), 2..16 = fixed. */
+ * 1 = off (one update pass per pivot), 2..32 = fixed. */
 int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep);
 /* The value in effect (after the by-size choice): 1 = one update pass per pivot, K > 1 = K pivots per sweep. */
 int lpx_state_get_block(const lpx_state* s);
@@ -192,7 +192,7 @@ int lpx_shard_set_pipeline(lpx_state* s, int32_t mode);
 int lpx_shard_peek(lpx_state* s, double* d_candidate, int32_t slot, int32_t pending);
 int lpx_shard_decide(lpx_state* s, const double* d_gathered, int32_t nranks, int32_t slot);
 int lpx_shard_update(lpx_state* s, int32_t slot);
-/* Row-block shards, blocked form (see lpx_state_set_block): per block of K <= 16 decisions the host issues, for
+/* Row-block shards, blocked form (see lpx_state_set_block): per block of K <= 32 decisions the host issues, for
  * slot = 0..K-1,   lpx_shard_block_peek(s, cand, slot) -> all-gather of cand -> lpx_shard_block_decide(s, gathered,
  * G, slot),   then ONE lpx_shard_block_sweep(s, K) that applies the (valid) decided pivots to the shard's rows in
  * a single pass.  After lpx_shard_begin; everything on the handle's main stream; no host sync. */

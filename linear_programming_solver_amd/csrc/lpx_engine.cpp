@@ -485,7 +485,8 @@ static int choose_block(const lpx_state* s) {
     const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
     if (sweep_us < 15.0) K = 1;        // cache-resident tableaux: the two-launch loop wins
     else if (sweep_us < 50.0) K = 8;
-    else K = 16;
+    else if (sweep_us < 600.0) K = 16;
+    else K = 32;                       // the sweep is VALU-bound there (2 fp64 ops per entry per pivot), still a gain
   }
   return std::max(1, std::min(K, (int)lpxk::kBlockMax));
 }
@@ -584,7 +585,7 @@ extern "C" int lpx_shard_block_sweep(lpx_state* s, int32_t nslots) {
 
 extern "C" int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep) {
   if (!s || pivots_per_sweep < 0 || pivots_per_sweep > lpxk::kBlockMax)
-    return fail(LPX_BAD_ARGUMENT, "lpx_state_set_block: 0 (auto), 1 (off) .. 16");
+    return fail(LPX_BAD_ARGUMENT, "lpx_state_set_block: 0 (auto), 1 (off) .. 32");
   s->block = pivots_per_sweep;
   return 0;
 }

@@ -80,7 +80,7 @@ void launch_commit(const Buffers& B, int n, int m_global, const double* d_gather
 void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* prow_t, const double* col_t,
                  double* col_next, const LpxCtl* pend, double* d_candidate, hipStream_t s);
 // blocked pivoting: ring of pending pivots (see lpx_kernels.hip "blocked pivoting")
-constexpr int kBlockMax = 16;
+constexpr int kBlockMax = 32;
 struct BlockRing {
   double* prow;   // kBlockMax x ld : normalised pivot row of pending pivot s
   double* col;    // kBlockMax x mp : column e_s of the tableau just before pivot s

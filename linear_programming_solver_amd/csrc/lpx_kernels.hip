@@ -18,6 +18,7 @@
 #include "lpx_kernels.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(1024) void k_peek_pack(const double* __restrict__ A
 // result is bit-identical — but the HBM traffic per pivot is 16*m*n/K bytes instead of 16*m*n.  Pending
 // pivots live in a ring: prow_ring[s] (ld doubles), col_ring[s] (mp doubles: column e_s BEFORE pivot s),
 // ring[s] (LpxCtl-shaped parameter block written by finish_pivot).
-constexpr int kMaxBlock = 16;
+constexpr int kMaxBlock = 32;
 
 __global__ __launch_bounds__(256) void k_peek_multi(const double* __restrict__ A, int64_t ld,
                                                     const double* __restrict__ b, int m_local, int row0,
@@ -773,6 +774,10 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
 // Workgroup = rows_per_tile (<= 32) rows x 512 columns, thread = one 16-byte double2 per row; the thread's
 // slices of the K pivot rows stay in registers (2K doubles), the K x rows multipliers of the tile are staged
 // once in LDS (coalesced load, broadcast reads); rows go RB at a time to keep RB loads in flight per thread.
+// Cost: two fp64 VALU operations per entry per pivot (the product and the difference must stay two roundings,
+// so no FMA): measured ~8 cycles per wave-instruction, which makes the sweep VALU-bound from K ~ 16 on
+// (cfg4: 1.36 ms for one pass, 1.55 ms at K = 16, 2.4 ms at K = 32; a one-double-per-thread variant with
+// twice the occupancy was not faster).
 constexpr int kSweepMaxRows = 32;
 
 template <int K, bool NT>
@@ -1148,7 +1153,8 @@ void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local
   if (K <= 2) launch_sweep_k<2>(B, R, m_local, K, rows_per_tile, nt, s);
   else if (K <= 4) launch_sweep_k<4>(B, R, m_local, K, rows_per_tile, nt, s);
   else if (K <= 8) launch_sweep_k<8>(B, R, m_local, K, rows_per_tile, nt, s);
-  else launch_sweep_k<16>(B, R, m_local, K, rows_per_tile, nt, s);
+  else if (K <= 16) launch_sweep_k<16>(B, R, m_local, K, rows_per_tile, nt, s);
+  else launch_sweep_k<32>(B, R, m_local, K, rows_per_tile, nt, s);
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
                      R.col0, R.row0, R.mp, R.up, K);

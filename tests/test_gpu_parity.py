@@ -709,7 +709,7 @@ def test_restore_index_fault_is_reported(lps, decimal_goldens):
 
 
 # ------------------------------------------------------------------------------------ blocked pivoting
-@pytest.mark.parametrize("block", [2, 3, 4, 8, 16])
+@pytest.mark.parametrize("block", [2, 3, 4, 8, 16, 21, 32])
 @pytest.mark.parametrize("shape", [(50, 80), (257, 300), (200, 1100), (9, 2100)])
 def test_blocked_pivoting_is_bit_identical(lps, oracle, shape, block):
     """K pivot decisions from the stale tableau + one K-fold sweep must equal K separate updates bit for bit:
@@ -761,7 +761,7 @@ def test_blocked_pivoting_with_dantzig_and_full_solve(lps, oracle):
     st.close()
 
 
-@pytest.mark.parametrize("block", [2, 5, 16])
+@pytest.mark.parametrize("block", [2, 5, 16, 32])
 @pytest.mark.parametrize("nshards,shape,budget", [(2, (64, 100), -1), (4, (130, 513), 25), (8, (257, 2100), 12),
                                                   (3, (10, 40), -1), (5, (1000, 260), 40)])
 def test_blocked_pivoting_on_shards_matches_oracle(lps, oracle, nshards, shape, budget, block):
