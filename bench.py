@@ -238,7 +238,7 @@ def main():
         block = args.block
         if block < 0:   # one decision incl. the exchange ~60 us; a rank's sweep 16*m_local*n bytes at ~6 TB/s
             sweep_us = 16.0 * (r1 - r0) * n / 6.0e6
-            block = 1 if sweep_us <= 50.0 else (16 if sweep_us < 600.0 else 32)
+            block = 1 if sweep_us <= 50.0 else (16 if sweep_us < 250.0 else 32)
         eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank, pipeline=args.pipeline if block == 1 else 1)
         t_up = time.perf_counter() - t_up
         ex = DistExchange()

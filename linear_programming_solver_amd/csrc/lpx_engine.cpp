@@ -74,7 +74,7 @@ struct lpx_state {
   int pricing = 0;                  // 0 = reference rule (first positive), 1 = Dantzig (opt-in extension)
   // blocked pivoting (K decisions from the stale tableau, then one sweep): 0 = choose by size, 1 = off
   int block = 0;
-  int sweep_rows = 16;
+  int sweep_rows = 0;  // 0: launch_block_sweep chooses
   lpxk::BlockRing R{};
   double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
@@ -476,8 +476,9 @@ static int ensure_block_ring(lpx_state* s) {
 }
 
 // Pivots per sweep.  Measured on MI355X: one decision (peek + pack + commit, three latency-bound launches) costs
-// ~14 us + ~0.4 us per pending pivot whatever the size; a sweep moves the tableau once at ~5.6 TB/s; the
-// one-pass form costs one pass at ~6.3 TB/s + ~9 us per pivot.  Per pivot: blocked(K) ~ 14 + 0.2 K + sweep/K.
+// ~18 us + ~0.4 us per pending pivot whatever the size; a sweep moves the tableau once at ~5.6 TB/s up to K = 16
+// and at ~4.7 TB/s at K = 32 (there the 2K fp64 operations per entry co-limit it); the one-pass form costs one
+// pass at ~6.3 TB/s + ~9 us per pivot.  Per pivot: blocked(K) ~ 18 + 0.4 K/2 + sweep(K)/K.
 static int choose_block(const lpx_state* s) {
   int K = s->block;
   if (K == 0) K = env_int("LPX_BLOCK", 0);
@@ -485,8 +486,8 @@ static int choose_block(const lpx_state* s) {
     const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
     if (sweep_us < 15.0) K = 1;        // cache-resident tableaux: the two-launch loop wins
     else if (sweep_us < 50.0) K = 8;
-    else if (sweep_us < 600.0) K = 16;
-    else K = 32;                       // the sweep is VALU-bound there (2 fp64 ops per entry per pivot), still a gain
+    else if (sweep_us < 250.0) K = 16;
+    else K = 32;
   }
   return std::max(1, std::min(K, (int)lpxk::kBlockMax));
 }

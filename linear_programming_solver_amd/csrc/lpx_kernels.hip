@@ -771,14 +771,82 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
 // row, its entering column becomes -(col/p)).  Those positions (K rows and K columns) are recomputed afterwards
 // by k_block_fixup from the stale values that k_peek_multi / k_pack_multi saved, with the full case analysis;
 // no entry depends on another entry, so the garbage written there in between is never read.
-// Workgroup = rows_per_tile (<= 32) rows x 512 columns, thread = one 16-byte double2 per row; the thread's
+// Workgroup = rows_per_tile (<= 64) rows x 512 columns, thread = one 16-byte double2 per row; the thread's
 // slices of the K pivot rows stay in registers (2K doubles), the K x rows multipliers of the tile are staged
 // once in LDS (coalesced load, broadcast reads); rows go RB at a time to keep RB loads in flight per thread.
 // Cost: two fp64 VALU operations per entry per pivot (the product and the difference must stay two roundings,
 // so no FMA): measured ~8 cycles per wave-instruction, which makes the sweep VALU-bound from K ~ 16 on
 // (cfg4: 1.36 ms for one pass, 1.55 ms at K = 16, 2.4 ms at K = 32; a one-double-per-thread variant with
 // twice the occupancy was not faster).
-constexpr int kSweepMaxRows = 32;
+constexpr int kSweepMaxRows = 128;
+#ifndef LPX_SWEEP_D
+#define LPX_SWEEP_D 2
+#endif
+
+// Number of valid leading pending pivots (slots >= kmax were not decided this block): one parallel look at the
+// ring by the first wave instead of a chain of dependent loads.  Result valid in every thread.
+__device__ __forceinline__ int ring_count(const LpxCtl* __restrict__ ring, int kcap, int kmax, int* sh_np) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const bool ok = lane < kcap && lane < kmax && ring[lane].do_update != 0;
+    const unsigned long long mask = __ballot(ok);
+    if (lane == 0) *sh_np = (~mask == 0ull) ? 64 : (__ffsll((long long)~mask) - 1);
+  }
+  __syncthreads();
+  return *sh_np;
+}
+
+// The K-fold update of one batch of RB rows x one double2 held in registers; the multipliers come from LDS
+// (one 16-byte broadcast read = two rows).
+template <int K, int RB, bool ALL>
+__device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], const double (*sh_col)[kSweepMaxRows],
+                                            int np, int r0) {
+  if constexpr (ALL) {
+    // np == K: straight-line code with the LDS reads of step s+D issued before the arithmetic of step s (the
+    // compiler, minimising registers, otherwise puts every read right in front of its use and the wave eats the
+    // full LDS latency 2K times per batch — measured: the fp64 VALU then idles half of the time).
+    constexpr int D = LPX_SWEEP_D;  // read-ahead distance in steps
+    d2 cc[D + 1][RB / 2];
+#pragma unroll
+    for (int s = 0; s < D && s < K; ++s)
+#pragma unroll
+      for (int r = 0; r < RB; r += 2)
+        cc[s][r / 2] = *reinterpret_cast<const d2*>(&sh_col[s][(r0 + r) & (kSweepMaxRows - 1)]);
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      if (s + D < K) {
+#pragma unroll
+        for (int r = 0; r < RB; r += 2)
+          cc[(s + D) % (D + 1)][r / 2] =
+              *reinterpret_cast<const d2*>(&sh_col[s + D][(r0 + r) & (kSweepMaxRows - 1)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < RB; r += 2) {
+        const d2 c2 = cc[s % (D + 1)][r / 2];
+        x[r].x = __dsub_rn(x[r].x, __dmul_rn(c2.x, pr[s].x));                      // LPState.java:162
+        x[r].y = __dsub_rn(x[r].y, __dmul_rn(c2.x, pr[s].y));
+        x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(c2.y, pr[s].x));
+        x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(c2.y, pr[s].y));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      if (s < np) {  // wave-uniform
+#pragma unroll
+        for (int r = 0; r < RB; r += 2) {
+          const d2 c2 = *reinterpret_cast<const d2*>(&sh_col[s][(r0 + r) & (kSweepMaxRows - 1)]);  // LDS broadcast
+          x[r].x = __dsub_rn(x[r].x, __dmul_rn(c2.x, pr[s].x));
+          x[r].y = __dsub_rn(x[r].y, __dmul_rn(c2.x, pr[s].y));
+          x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(c2.y, pr[s].x));
+          x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(c2.y, pr[s].y));
+        }
+      }
+    }
+  }
+}
 
 template <int K, bool NT>
 __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, int64_t ld, int m_local,
@@ -788,59 +856,97 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
                                                       int rows_per_tile, int nstrips) {
   __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
-  if (threadIdx.x == 0) {
-    int cnt = 0;
-    while (cnt < K && cnt < kmax && ring[cnt].do_update != 0) ++cnt;  // slots >= kmax were not decided this block
-    sh_np = cnt;
-  }
-  __syncthreads();
-  const int np = sh_np;
-  if (np == 0) return;
+  constexpr int RB = (K <= 8) ? 8 : 4;   // rows per batch (register budget: 2K doubles of pivot rows)
   const int strip = blockIdx.x % nstrips;
   const int tile = blockIdx.x / nstrips;
   const int cj = strip * 512 + 2 * threadIdx.x;
   const bool act = cj < (int)ld;
   const int r_begin = tile * rows_per_tile;
   const int nrows = min(m_local, r_begin + rows_per_tile) - r_begin;
+  // uniform tile base (SGPRs) + 32-bit per-lane byte offset: one VGPR per address
+  char* const tile_base = reinterpret_cast<char*>(A + (int64_t)r_begin * ld + strip * 512);
+  const uint32_t row_bytes = (uint32_t)ld * 8u;  // the launcher checks rows_per_tile * ld * 8 < 2^32
+  const uint32_t off0 = threadIdx.x * 16u;
+
+  // Prologue: everything the workgroup needs is requested at once — the ring's flags, the multipliers, the
+  // thread's slices of the K pivot rows and the first batch of rows — ONE memory round trip, not four.
+  bool ok = false;
+  if (threadIdx.x < 64) ok = (int)threadIdx.x < K && (int)threadIdx.x < kmax && ring[threadIdx.x].do_update != 0;
   for (int idx = threadIdx.x; idx < K * kSweepMaxRows; idx += blockDim.x) {
     const int sidx = idx / kSweepMaxRows, r = idx % kSweepMaxRows;
-    sh_col[sidx][r] = (sidx < np && r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;
+    sh_col[sidx][r] = (r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;  // slots >= np: never used
   }
   d2 pr[K];
 #pragma unroll
   for (int s = 0; s < K; ++s)
-    pr[s] = (s < np && act) ? *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj) : d2{0.0, 0.0};
-  __syncthreads();  // sh_col complete
+    pr[s] = act ? *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj) : d2{0.0, 0.0};
+  // Full strips (all but possibly the last one of a row) with at least one full batch take the fast path below.
+  const bool fast_geom = (strip + 1) * 512 <= (int)ld && nrows >= RB;
+  d2 x[RB], xn[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    x[r] = d2{0.0, 0.0};
+    if (fast_geom) {  // uniform
+      const d2* q = reinterpret_cast<const d2*>(tile_base + (off0 + (uint32_t)r * row_bytes));
+      x[r] = NT ? __builtin_nontemporal_load(q) : *q;
+    }
+  }
+  if (threadIdx.x < 64) {
+    const unsigned long long mask = __ballot(ok);
+    if (threadIdx.x == 0) sh_np = (~mask == 0ull) ? 64 : (__ffsll((long long)~mask) - 1);
+  }
+  __syncthreads();  // sh_col and sh_np complete
+  const int np = sh_np;
+  if (np == 0) return;
 
-  constexpr int RB = (K <= 8) ? 8 : 4;   // rows in flight per thread (register budget: 2K doubles of pivot rows)
-  for (int r0 = 0; r0 < nrows; r0 += RB) {
-    d2 x[RB];
+  // Fast path, the steady state (np == K): straight-line batches without any per-lane guard, software-pipelined
+  // — the next batch's loads are in flight while this one runs its 2K fp64 operations per entry.
+  const int full = (fast_geom && np == K) ? nrows / RB : 0;
+  if (full > 0) {
+#pragma unroll 1
+    for (int bt = 0; bt + 1 < full; ++bt) {
+      const int r0 = bt * RB;
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      x[r] = d2{0.0, 0.0};
-      if (r0 + r < nrows && act) {
-        const d2* q = reinterpret_cast<const d2*>(A + (int64_t)(r_begin + r0 + r) * ld + cj);
-        x[r] = NT ? __builtin_nontemporal_load(q) : *q;
+      for (int r = 0; r < RB; ++r) {
+        const d2* q = reinterpret_cast<const d2*>(tile_base + (off0 + (uint32_t)(r0 + RB + r) * row_bytes));
+        xn[r] = NT ? __builtin_nontemporal_load(q) : *q;
       }
-    }
+      sweep_apply<K, RB, true>(x, pr, sh_col, np, r0);
 #pragma unroll
-    for (int s = 0; s < K; ++s) {
-      if (s < np) {  // wave-uniform
-#pragma unroll
-        for (int r = 0; r < RB; r += 2) {
-          const d2 cc = *reinterpret_cast<const d2*>(&sh_col[s][(r0 + r) & (kSweepMaxRows - 1)]);  // LDS broadcast
-          x[r].x = __dsub_rn(x[r].x, __dmul_rn(cc.x, pr[s].x));                    // LPState.java:162
-          x[r].y = __dsub_rn(x[r].y, __dmul_rn(cc.x, pr[s].y));
-          x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(cc.y, pr[s].x));
-          x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(cc.y, pr[s].y));
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      if (r0 + r < nrows && act) {
-        d2* q = reinterpret_cast<d2*>(A + (int64_t)(r_begin + r0 + r) * ld + cj);
+      for (int r = 0; r < RB; ++r) {
+        d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
         if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) x[r] = xn[r];
+    }
+    {  // last full batch: nothing left to prefetch
+      const int r0 = (full - 1) * RB;
+      sweep_apply<K, RB, true>(x, pr, sh_col, np, r0);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+        if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
+      }
+    }
+  }
+  // the rest (partial blocks, rows beyond the last full batch, the partial last strip): guarded
+  for (int r0 = full * RB; r0 < nrows; r0 += RB) {
+    d2 y[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      y[r] = d2{0.0, 0.0};
+      if (r0 + r < nrows && act) {
+        const d2* q = reinterpret_cast<const d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+        y[r] = NT ? __builtin_nontemporal_load(q) : *q;
+      }
+    }
+    sweep_apply<K, RB, false>(y, pr, sh_col, np, r0);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      if (r0 + r < nrows && act) {
+        d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+        if (NT) __builtin_nontemporal_store(y[r], q); else *q = y[r];
       }
     }
   }
@@ -867,13 +973,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
   __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
   __shared__ int sh_np;
   const int s = blockIdx.y, job = blockIdx.z;
-  if (threadIdx.x == 0) {
-    int cnt = 0;
-    while (cnt < kMaxBlock && cnt < kmax && ring[cnt].do_update != 0) ++cnt;
-    sh_np = cnt;
-  }
-  __syncthreads();
-  const int np = sh_np;
+  const int np = ring_count(ring, kMaxBlock, kmax, &sh_np);
   if (s >= np || (job == 2 && s != 0)) return;
   if ((int)threadIdx.x < np) {
     const LpxCtl& q = ring[threadIdx.x];
@@ -1145,11 +1245,24 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
                        R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
 }
 
+// rows_per_tile <= 0: chosen here from measurements (profiles/r01_sweep_rows.txt).  Up to K = 16 the sweep is
+// HBM-bound and 16-row tiles stream best (larger tiles widen the set of DRAM pages in flight: -10 %).  At K = 32
+// it is co-limited by the fp64 VALU, the per-workgroup prologue (2K doubles of pivot rows per thread) weighs more,
+// and 64-row tiles win (+20 % over 16) as long as the grid still has a few thousand workgroups.
 void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
                         bool nt, hipStream_t s) {
-  if (m_local <= 0) return;
+  if (K < 1) return;
+  if (rows_per_tile <= 0) {
+    const int64_t nstrips = (B.ld + 511) / 512;
+    rows_per_tile = 16;
+    if (K > 16) {
+      for (int rows : {64, 32}) {
+        if ((int64_t)((m_local + rows - 1) / rows) * nstrips >= 4096) { rows_per_tile = rows; break; }
+      }
+    }
+  }
   rows_per_tile = std::max(8, std::min(rows_per_tile, kSweepMaxRows)) & ~7;  // rows go four or eight at a time
-  K = std::min(K, (int)kMaxBlock);
+  while (rows_per_tile > 8 && (int64_t)rows_per_tile * B.ld * 8 >= (int64_t)1 << 32) rows_per_tile -= 8;  // 32-bit offsets
   if (K <= 2) launch_sweep_k<2>(B, R, m_local, K, rows_per_tile, nt, s);
   else if (K <= 4) launch_sweep_k<4>(B, R, m_local, K, rows_per_tile, nt, s);
   else if (K <= 8) launch_sweep_k<8>(B, R, m_local, K, rows_per_tile, nt, s);
