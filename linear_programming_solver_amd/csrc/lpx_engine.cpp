@@ -166,6 +166,14 @@ static void free_state(lpx_state* s) {
   (void)hipFree(s->R.col0);
   (void)hipFree(s->R.row0);
   (void)hipFree(s->R.up);
+  (void)hipFree(s->R.chain_part_a);
+  (void)hipFree(s->R.chain_part_b);
+  (void)hipFree(s->R.chain_bar);
+  (void)hipFree(s->R.chain_own_col);
+  (void)hipFree(s->R.chain_own_prow);
+  (void)hipFree(s->R.chain_own_dvc);
+  (void)hipFree(s->R.chain_own_b);
+  (void)hipFree(s->R.chain_dbg);
   (void)hipFree(s->d_cand);
   if (s->ev_upd) (void)hipEventDestroy(s->ev_upd);
 
@@ -467,6 +475,20 @@ static int ensure_block_ring(lpx_state* s) {
   HIP_TRY(hipMemsetAsync(s->R.col0, 0, K * (size_t)mp * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.row0, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.up, K * sizeof(LpxCtl)));
+  HIP_TRY(hipMalloc(&s->R.chain_part_a, lpxk::kChainMaxWgs * 32));
+  HIP_TRY(hipMalloc(&s->R.chain_part_b, lpxk::kChainMaxWgs * 16));
+  HIP_TRY(hipMalloc((void**)&s->R.chain_bar, 16));
+  HIP_TRY(hipMemsetAsync(s->R.chain_bar, 0, 16, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.chain_own_col, K * (size_t)mp * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s->R.chain_own_prow, K * (size_t)s->B.ld * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s->R.chain_own_dvc, K * (size_t)mp * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s->R.chain_own_b, (size_t)mp * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(s->R.chain_own_col, 0, K * (size_t)mp * sizeof(double), s->stream));
+  HIP_TRY(hipMemsetAsync(s->R.chain_own_prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
+  if (getenv("LPX_CHAIN_TRACE")) {
+    HIP_TRY(hipMalloc((void**)&s->R.chain_dbg, 5 * lpxk::kBlockMax * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(s->R.chain_dbg, 0, 5 * lpxk::kBlockMax * sizeof(long long), s->stream));
+  }
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));
@@ -521,19 +543,29 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   hipEvent_t* evs = s->ev_batch;
   LpxCtl* h2 = s->h_snap;
   int64_t decided = 0;  // decisions issued (each either pivots or reports the end)
+  // one persistent launch per block (k_block_chain) instead of three launches per decision; LPX_CHAIN=0: off
+  const bool fused = env_int("LPX_CHAIN", 1) != 0 && s->row0 == 0 && s->m == s->m_global;
+  const int chain_wgs = env_int("LPX_CHAIN_WGS", 0);
+  LpxCtl* d_snap = nullptr;  // the pinned snapshots as the device sees them
+  if (fused) HIP_TRY(hipHostGetDevicePointer((void**)&d_snap, s->h_snap, 0));
   auto issue_block = [&](int slot) -> int {
     int nb = K;
     if (max_pivots >= 0) nb = (int)std::max<int64_t>(0, std::min<int64_t>(nb, max_pivots + 1 - decided));
-    for (int k = 0; k < nb; k++) {
-      lpxk::launch_block_peek(s->B, s->R, s->n, s->m, s->row0, k, s->d_cand, s->stream);
-      lpxk::launch_block_decide(s->B, s->R, s->n, s->m_global, s->d_cand, 1, k, s->stream);
-      if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, false, s->stream);
+    if (fused && nb > 0) {
+      lpxk::launch_block_chain(s->B, s->R, s->n, s->m, nb, s->pricing == 1, chain_wgs, d_snap + slot, s->stream);
+    } else {
+      for (int k = 0; k < nb; k++) {
+        lpxk::launch_block_peek(s->B, s->R, s->n, s->m, s->row0, k, s->d_cand, s->stream);
+        lpxk::launch_block_decide(s->B, s->R, s->n, s->m_global, s->d_cand, 1, k, s->stream);
+        if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, false, s->stream);
+      }
     }
     decided += nb;
     if (nb > 0) {
       if (int rc = launch_sweep_profiled(s, nb)) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(&h2[slot], s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
+    if (!(fused && nb > 0))  // the fused launch writes the snapshot itself
+      HIP_TRY(hipMemcpyAsync(&h2[slot], s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipEventRecord(evs[slot], s->stream));
     return 0;
   };
@@ -549,6 +581,16 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   }
   hipError_t e2 = hipStreamSynchronize(s->stream);
   if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
+  if (rc == 0 && s->R.chain_dbg) {  // LPX_CHAIN_TRACE=<file>: phase timestamps (100 MHz ticks) of the last block
+    long long h[5 * lpxk::kBlockMax];
+    if (hipMemcpy(h, s->R.chain_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE* f = fopen(getenv("LPX_CHAIN_TRACE"), "w")) {
+        for (int k = 0; k < lpxk::kBlockMax; k++)
+          fprintf(f, "%d %lld %lld %lld %lld %lld\n", k, h[5 * k], h[5 * k + 1], h[5 * k + 2], h[5 * k + 3], h[5 * k + 4]);
+        fclose(f);
+      }
+    }
+  }
   return rc;
 }
 

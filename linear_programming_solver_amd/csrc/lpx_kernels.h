@@ -88,12 +88,26 @@ struct BlockRing {
   double* row0;   // kBlockMax x ld : the stale pivot row l_s (for the fix-up)
   LpxCtl* up;     // kBlockMax parameter blocks (written by finish_pivot)
   int64_t mp;
+  // scratch of k_block_chain (single-shard blocks decided in one persistent launch)
+  void* chain_part_a;      // kChainMaxWgs x 32 B
+  void* chain_part_b;      // kChainMaxWgs x 16 B
+  unsigned* chain_bar;     // 16 B, zeroed before every launch
+  double* chain_own_col;   // kBlockMax x mp: copy of `col` that only its writer re-reads (plain, cache-resident)
+  double* chain_own_prow;  // kBlockMax x ld: likewise for `prow`
+  double* chain_own_dvc;   // kBlockMax x mp: column e_s of the tableau just AFTER pivot s (restart point)
+  double* chain_own_b;     // mp: b with all pending pivots applied
+  long long* chain_dbg;    // diagnostics (LPX_CHAIN_TRACE): 5 timestamps per decision of the last block, else NULL
 };
+constexpr int kChainMaxWgs = 256;   // <= one workgroup per CU: the whole grid is resident
 // decision number `np` of a block (np pivots pending): candidate record like k_propose's
 void launch_block_peek(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int np, double* d_candidate,
                        hipStream_t s);
 void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_global, const double* d_gathered, int nranks,
                          int slot, hipStream_t s);
+// all nb decisions of a block in one persistent launch (single shard: row0 == 0, m == m_global); wgs <= 0: auto
+// host_snap: device-visible pointer to a pinned host LpxCtl that receives the loop state when the launch ends
+void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int dantzig, int wgs,
+                        LpxCtl* host_snap, hipStream_t s);
 // apply the valid leading pending pivots (at most K) in one pass
 void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
                         bool nt, hipStream_t s);

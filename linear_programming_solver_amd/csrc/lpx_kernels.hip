@@ -766,6 +766,343 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
   }
 }
 
+// ------------------------------------------------------------------------------------------------ k_block_chain
+// All decisions of one block in ONE launch (one shard owning every row, i.e. the single-GPU loop).  The three
+// launches per decision above are latency chains (status -> entering slot -> column -> ratio -> row -> ...), ~6 us
+// each however little they compute; here the same steps run inside a persistent grid of <= 256 workgroups (one
+// per CU at most, so every workgroup is resident) separated by two grid barriers per decision:
+//
+//   phase A  every thread owns rows i = gid, gid+T, ...: column e of the tableau with the s pending pivots applied
+//            (stale column + s sequential corrections, as k_peek_multi), ratio test, workgroup minimum -> partA[wg]
+//   barrier
+//   phase B  every workgroup reduces partA to the leaving row l (same data, same result everywhere); every thread
+//            owns columns j = gid, gid+T, ...: row l with the s pending pivots applied (as k_pack_multi), normalised
+//            row, update of c, candidate for the next entering slot (as finish_pivot) -> partB[wg]; workgroup 0's
+//            first thread updates v, perm, the tracked slot and the ring's parameter block
+//   barrier  every workgroup reduces partB to the next entering slot.
+//
+// Ownership is fixed for the whole launch, so a thread re-reads only ring entries it wrote itself; what crosses
+// workgroups (the partial records, c[e], prow_s[e], col_s[l]) is read with agent-scope loads behind an agent-scope
+// release / acquire pair around the barrier's counter (MI355X: per-XCD L2s are not coherent with each other).
+// The arithmetic is statement for statement that of k_peek_multi / k_pack_multi / finish_pivot.
+struct ChainPart {
+  double ratio, a, bi;
+  int32_t row, pad;
+};
+
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// write-through store (sc1): the line does not stay dirty in this XCD's L2, so the barrier's release has nothing
+// to write back
+__device__ __forceinline__ void st_agent(double* p, double x) {
+  __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(int32_t* p, int32_t x) {
+  __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Monotonic-counter grid barrier.  Every wave drains its stores, the workgroup meets, one lane publishes with an
+// agent-scope release, arrives, polls (relaxed, bounded) and acquires; the second workgroup barrier holds the other
+// waves until the invalidate has completed.  Returns false when the spin bound was hit (never in a healthy run:
+// it only keeps a bug from hanging the device).  fences: bit 0 = release fence, bit 1 = acquire fence.
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* sh_fail, int fences) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (fences & 1) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 22)) { *sh_fail = 1; break; }
+    }
+    if (fences & 2) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  return *sh_fail == 0;
+}
+
+// One pending pivot r applied to the entering-column value of row i (phase A) / to the row value of column j
+// (phase B).  `on` is wave-uniform: steps outside (restart, s) leave the value alone.
+#define LPX_CHAIN_STEP_A(r, on, cs_r, pe_r, l_r)                                   \
+  {                                                                                \
+    const double t_ = __dsub_rn(a, __dmul_rn((cs_r), (pe_r)));                     \
+    const double nv_ = (i == (l_r)) ? (pe_r) : t_;                                 \
+    a = (on) ? nv_ : a;                                                            \
+  }
+#define LPX_CHAIN_STEP_B(r, on, cs_r, prv_r, e_r, dv_r)                            \
+  {                                                                                \
+    const double t_ = __dsub_rn(x, __dmul_rn((cs_r), (prv_r)));                    \
+    const double nv_ = (j == (e_r)) ? (dv_r) : t_;                                 \
+    x = (on) ? nv_ : x;                                                            \
+  }
+
+// The host's view of the loop (status, pivots, ...) goes straight into its pinned snapshot: no copy-engine
+// transfer (and its ~40 us of stream idle time) per block.  Called by the one thread that wrote ctl.
+__device__ __forceinline__ void chain_publish(const LpxCtl* ctl, LpxCtl* host_snap) {
+  if (!host_snap) return;
+  *host_snap = *ctl;
+  __threadfence_system();
+}
+
+__global__ __launch_bounds__(256) void k_block_chain(const double* __restrict__ A, int64_t ld, int n, int m,
+                                                     const double* __restrict__ b, double* c, double* prow_ring,
+                                                     double* col_ring, double* col0_ring, double* row0_ring,
+                                                     int64_t mp, LpxCtl* ring, int nb, int32_t* perm, LpxCtl* ctl,
+                                                     ChainPart* partA, RatioRow* partB, unsigned* bar, int dantzig,
+                                                     int fences, double* own_col, double* own_prow, double* own_dvc,
+                                                     double* own_b, LpxCtl* host_snap, long long* dbg) {
+  __shared__ RatioRow sh_rr[4];
+  __shared__ double sh_pe[kMaxBlock], sh_cs[kMaxBlock], sh_dv[kMaxBlock], sh_p[kMaxBlock], sh_bl[kMaxBlock], sh_win[2];
+  __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
+  __shared__ int sh_fail, sh_restart;
+  const int G = gridDim.x, T = G * 256, tid = threadIdx.x, gid = blockIdx.x * 256 + tid;
+  const bool lead = gid == 0;
+  if (tid == 0) sh_fail = 0;
+  // loop state at entry: written by earlier launches, identical in every workgroup
+  int e = ctl->e_next;
+  if (ctl->status != kRunning || e < 0 || nb < 1) {
+    if (lead && nb >= 1) ring[0].do_update = 0;
+    if (lead) chain_publish(ctl, host_snap);
+    return;
+  }
+  int64_t pivots = ctl->pivots;
+  const int64_t max_pivots = ctl->max_pivots;
+  double v = ctl->v;
+  int track = ctl->track, parity = ctl->parity;
+  unsigned target = 0;
+
+  for (int s = 0; s < nb; ++s) {
+    // ------------------------------------------------------------------ phase A: column e, ratio test
+    // Column e of the tableau with the s pending pivots applied = the stale column run through pivots 0..s-1 in
+    // order.  If an earlier pivot r* of this block entered at the same slot, its update REPLACED the column by
+    // -(col/p) (1/p in its own row) whatever it was before: the chain restarts there, from own_dvc[r*], and
+    // only pivots r* < r < s remain — so every step has the one generic form and the loop is branch-free.
+    // b needs no chain at all: own_b holds it with all pending pivots applied (one step added per decision).
+    if (dbg && lead) dbg[s * 5 + 0] = wall_clock64();
+    const double pc = ld_agent(&c[e]);  // c[e] is rewritten only in phase B, after the next barrier
+    if (tid < 64) {
+      bool same = false;
+      if (tid < s) {
+        sh_pe[tid] = ld_agent(&prow_ring[(int64_t)tid * ld + e]);  // one wave per workgroup, not every thread
+        same = sh_e[tid] == e;
+      }
+      const unsigned long long mask = __ballot(same);
+      if (tid == 0) sh_restart = mask ? 63 - __clzll((long long)mask) : -1;
+    }
+    __syncthreads();
+    const int ra = sh_restart;
+    RatioRow best = rr_none();
+    double best_a = 0.0, best_b = 0.0;
+    for (int i = gid; i < m; i += T) {
+      const double a_stale = A[(int64_t)i * ld + e];
+      const double* src_a = (ra >= 0) ? &own_dvc[(int64_t)ra * mp + i] : &A[(int64_t)i * ld + e];
+      const double* src_b = (s > 0) ? &own_b[i] : &b[i];
+      double a = *src_a;
+      const double bi = *src_b;
+      double cs[kMaxBlock];  // this thread's own stores; no branch around a load (slots >= s re-read slot 0, unused)
+#pragma unroll
+      for (int q = 0; q < kMaxBlock; ++q) cs[q] = own_col[(int64_t)((q < s) ? q : 0) * mp + i];
+      st_agent(&col0_ring[(int64_t)s * mp + i], a_stale);  // the stale column, kept for k_block_fixup
+#pragma unroll
+      for (int r0 = 0; r0 < kMaxBlock; r0 += 8) {
+        if (r0 < s && r0 + 8 > ra + 1) {  // uniform: the chunk meets (ra, s)
+          double pe8[8];  // the chunk's parameters first, then the arithmetic: the LDS latencies overlap
+          int l8[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { pe8[q] = sh_pe[r0 + q]; l8[q] = sh_l[r0 + q]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) LPX_CHAIN_STEP_A(r0 + q, (r0 + q > ra && r0 + q < s), cs[r0 + q], pe8[q], l8[q])
+        }
+      }
+      st_agent(&col_ring[(int64_t)s * mp + i], a);
+      own_col[(int64_t)s * mp + i] = a;
+      const double rt = ratio_of(a, bi);
+      if (rt < best.ratio) {  // i ascends per thread: strict < keeps the lowest row among equal ratios
+        best = RatioRow{rt, i, 0};
+        best_a = a;
+        best_b = bi;
+      }
+    }
+    {
+      const RatioRow w = rr_block_min(best, sh_rr);
+      if (w.row != INT_MAX && best.row == w.row) { sh_win[0] = best_a; sh_win[1] = best_b; }
+      __syncthreads();
+      if (tid == 0) {
+        ChainPart* rec = &partA[blockIdx.x];
+        st_agent(&rec->ratio, w.ratio);
+        st_agent(&rec->row, w.row);
+        st_agent(&rec->a, (w.row != INT_MAX) ? sh_win[0] : 0.0);
+        st_agent(&rec->bi, (w.row != INT_MAX) ? sh_win[1] : 0.0);
+      }
+    }
+    if (dbg && lead) dbg[s * 5 + 1] = wall_clock64();
+    target += (unsigned)G;
+    if (!grid_barrier(bar, target, &sh_fail, fences)) { if (lead) { ctl->status = 7 /* LPX_DEVICE_ERROR */; chain_publish(ctl, host_snap); } return; }
+    if (dbg && lead) dbg[s * 5 + 2] = wall_clock64();
+
+    // ------------------------------------------------------------------ phase B: the leaving row
+    RatioRow mine = rr_none();
+    double mine_a = 0.0, mine_b = 0.0;
+    if (tid < G) {
+      mine.ratio = ld_agent(&partA[tid].ratio);
+      mine.row = ld_agent(&partA[tid].row);
+      mine_a = ld_agent(&partA[tid].a);
+      mine_b = ld_agent(&partA[tid].bi);
+    }
+    const RatioRow w = rr_block_min(mine, sh_rr);
+    if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
+    __syncthreads();
+    if (w.row == INT_MAX || !(w.ratio < kInf)) {  // getLeaving() == -1: unbounded
+      if (lead) {
+        ctl->status = 1; ctl->do_update = 0; ctl->l = -1; ctl->ratio = w.ratio; ring[s].do_update = 0;
+        chain_publish(ctl, host_snap);
+      }
+      return;
+    }
+    if (max_pivots >= 0 && pivots >= max_pivots) {
+      if (lead) {
+        ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; ring[s].do_update = 0;
+        chain_publish(ctl, host_snap);
+      }
+      return;
+    }
+    const int l = w.row;
+    const double p = sh_win[0], raw_b = sh_win[1];
+    if (p == 0.0) {  // ArithmeticException in the reference, LPState.java:139
+      if (lead) { ctl->status = 8; ctl->do_update = 0; ring[s].do_update = 0; chain_publish(ctl, host_snap); }
+      return;
+    }
+    // Row l with the s pending pivots applied; an earlier pivot r* with the same leaving row REPLACED the row by
+    // its normalised row: restart there (own_prow[r*]).  Column e_r of the row becomes -(col_r[l]/p_r) at pivot r.
+    if (tid < 64) {
+      bool same = false;
+      if (tid < s) {
+        const double csv = ld_agent(&col_ring[(int64_t)tid * mp + l]);
+        sh_cs[tid] = csv;
+        sh_dv[tid] = -__ddiv_rn(csv, sh_p[tid]);
+        same = sh_l[tid] == l;
+      }
+      const unsigned long long mask = __ballot(same);
+      if (tid == 0) sh_restart = mask ? 63 - __clzll((long long)mask) : -1;
+    }
+    __syncthreads();
+    const int rb = sh_restart;
+    const double bl = __ddiv_rn(raw_b, p);                                         // :146
+    const double inv_p = __ddiv_rn(1.0, p);                                        // :139
+    // the row owners add pivot s to their two running columns: the entering column after the pivot (what a later
+    // decision restarts from) and b
+    for (int i = gid; i < m; i += T) {
+      const double colv = own_col[(int64_t)s * mp + i];
+      const double* src_b = (s > 0) ? &own_b[i] : &b[i];
+      const double bcur = *src_b;
+      own_dvc[(int64_t)s * mp + i] = (i == l) ? inv_p : -__ddiv_rn(colv, p);      // :157 / :139
+      own_b[i] = (i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));            // :146 / :164
+    }
+    RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
+    const double* rowl = A + (int64_t)l * ld;
+    for (int j = gid; j < (int)ld; j += T) {
+      double x = 0.0;
+      const double cj = ld_agent(&c[j]);  // this thread's own store (or the initial value)
+      if (j < n) {
+        const double x_stale = rowl[j];
+        const double* src_x = (rb >= 0) ? &own_prow[(int64_t)rb * ld + j] : &rowl[j];
+        x = *src_x;
+        double prv[kMaxBlock];  // this thread's own stores
+#pragma unroll
+        for (int q = 0; q < kMaxBlock; ++q) prv[q] = own_prow[(int64_t)((q < s) ? q : 0) * ld + j];
+        st_agent(&row0_ring[(int64_t)s * ld + j], x_stale);  // the stale row, kept for k_block_fixup
+#pragma unroll
+        for (int r0 = 0; r0 < kMaxBlock; r0 += 8) {
+          if (r0 < s && r0 + 8 > rb + 1) {
+            double cs8[8], dv8[8];
+            int e8[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { cs8[q] = sh_cs[r0 + q]; dv8[q] = sh_dv[r0 + q]; e8[q] = sh_e[r0 + q]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+              LPX_CHAIN_STEP_B(r0 + q, (r0 + q > rb && r0 + q < s), cs8[q], prv[r0 + q], e8[q], dv8[q])
+          }
+        }
+      }
+      double cn, pr;
+      if (j == e) {
+        pr = inv_p;
+        cn = -__ddiv_rn(pc, p);                                                    // :172
+      } else {
+        pr = __ddiv_rn(x, p);                                                      // :144
+        cn = __dsub_rn(cj, __dmul_rn(pc, pr));                                     // :177
+      }
+      st_agent(&prow_ring[(int64_t)s * ld + j], pr);
+      own_prow[(int64_t)s * ld + j] = pr;
+      st_agent(&c[j], cn);
+      if (j < n && cn > kEps) {
+        const RatioRow k2{dantzig ? -cn : 0.0, j, 0};
+        cand = rr_min(cand, k2);
+      }
+    }
+    {
+      const RatioRow w2 = rr_block_min(cand, sh_rr);
+      if (tid == 0) {
+        st_agent(&partB[blockIdx.x].ratio, w2.ratio);
+        st_agent(&partB[blockIdx.x].row, w2.row);
+        sh_e[s] = e; sh_l[s] = l; sh_p[s] = p; sh_bl[s] = bl;
+      }
+    }
+    if (lead) {
+      v = __dadd_rn(v, __dmul_rn(bl, pc));                                         // :171
+      const int32_t perm_e = perm[e], perm_l = perm[n + l];                        // exchangeIndexes :311-320
+      perm[e] = perm_l;
+      perm[n + l] = perm_e;
+      if (track >= 0) {                                                            // LPSolver.java:151-155
+        if (e == track) track = l + n;
+        else if (l + n == track) track = e;
+      }
+      LpxCtl& up = ring[s];
+      up.p = p; up.bl = bl; up.e_cur = e; up.l = l; up.e_next = -1; up.parity = 0; up.do_update = 1;
+    }
+    if (dbg && lead) dbg[s * 5 + 3] = wall_clock64();
+    target += (unsigned)G;
+    if (!grid_barrier(bar, target, &sh_fail, fences)) { if (lead) { ctl->status = 7; chain_publish(ctl, host_snap); } return; }
+    if (dbg && lead) dbg[s * 5 + 4] = wall_clock64();
+
+    RatioRow m2 = rr_none();
+    if (tid < G) { m2.ratio = ld_agent(&partB[tid].ratio); m2.row = ld_agent(&partB[tid].row); }
+    const RatioRow w3 = rr_block_min(m2, sh_rr);
+    const int e_next = (w3.row == INT_MAX) ? -1 : w3.row;
+    pivots += 1;
+    parity ^= 1;
+    if (lead) {
+      ctl->v = v; ctl->p = p; ctl->bl = bl; ctl->pc = pc; ctl->ratio = w.ratio;
+      ctl->e_cur = e; ctl->l = l; ctl->e_next = e_next; ctl->parity = parity; ctl->pivots = pivots;
+      ctl->track = track; ctl->do_update = 1;
+      if (e_next < 0) {
+        ctl->status = 0 /* LPX_OPTIMAL once the sweep has applied this pivot */;
+        if (s + 1 < nb) ring[s + 1].do_update = 0;  // the block ends here: the sweep counts leading valid slots
+      }
+    }
+    if (e_next < 0 || s + 1 == nb) {
+      if (lead) chain_publish(ctl, host_snap);
+      return;
+    }
+    e = e_next;
+  }
+}
+#undef LPX_CHAIN_STEP_A
+#undef LPX_CHAIN_STEP_B
+
 // The sweep is a pure streaming kernel: x -= col_s[i] * prow_s[j] for the valid pending pivots s, in order, for
 // EVERY entry — also at the few positions where a pivot does something else (its own row becomes the normalised
 // row, its entering column becomes -(col/p)).  Those positions (K rows and K columns) are recomputed afterwards
@@ -968,8 +1305,11 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
                                                      const double* __restrict__ col_ring,
                                                      const double* __restrict__ col0_ring,
                                                      const double* __restrict__ row0_ring, int64_t mp,
-                                                     const LpxCtl* __restrict__ ring, int kmax) {
+                                                     const LpxCtl* __restrict__ ring, int kmax,
+                                                     unsigned* chain_bar) {
   __shared__ double sh_p[kMaxBlock], sh_bl[kMaxBlock], sh_x[kMaxBlock];
+  if (chain_bar && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+    *chain_bar = 0;  // the next k_block_chain's grid-barrier counter
   __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
   __shared__ int sh_np;
   const int s = blockIdx.y, job = blockIdx.z;
@@ -1232,6 +1572,20 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
                      R.prow + (int64_t)slot * B.ld, B.perm, B.ctl, R.up + slot, 0);
 }
 
+void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int dantzig, int wgs,
+                        LpxCtl* host_snap, hipStream_t s) {
+  static const int fences = getenv("LPX_CHAIN_FENCES") ? atoi(getenv("LPX_CHAIN_FENCES")) : 3;
+  const int64_t work = std::max<int64_t>(m, B.ld);
+  // two rows / columns per thread: measured best (a grid barrier costs ~1 us at 32 workgroups, ~4 us at 128)
+  int G = wgs > 0 ? wgs : (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 511) / 512));
+  G = std::max(1, std::min(G, kChainMaxWgs));
+  // R.chain_bar is zero here: zeroed at allocation and again by every k_block_fixup, which follows every chain
+  hipLaunchKernelGGL(k_block_chain, dim3(G), dim3(256), 0, s, B.A, B.ld, n, m, B.b, B.c, R.prow, R.col, R.col0, R.row0,
+                     R.mp, R.up, nb, B.perm, B.ctl, reinterpret_cast<ChainPart*>(R.chain_part_a),
+                     reinterpret_cast<RatioRow*>(R.chain_part_b), R.chain_bar, dantzig, fences, R.chain_own_col, R.chain_own_prow, R.chain_own_dvc,
+                     R.chain_own_b, host_snap, R.chain_dbg);
+}
+
 template <int K>
 static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_tile, bool nt,
                            hipStream_t s) {
@@ -1270,7 +1624,7 @@ void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local
   else launch_sweep_k<32>(B, R, m_local, K, rows_per_tile, nt, s);
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
-                     R.col0, R.row0, R.mp, R.up, K);
+                     R.col0, R.row0, R.mp, R.up, K, R.chain_bar);
 }
 
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {
