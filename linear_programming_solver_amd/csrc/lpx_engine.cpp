@@ -76,6 +76,10 @@ struct lpx_state {
   int block = 0;
   int sweep_rows = 0;  // 0: launch_block_sweep chooses
   lpxk::BlockRing R{};
+  int chain_seq = 0;                // k_block_chain launches so far (its two barrier counters alternate)
+  // overlapped blocked loop: decisions of block k+1 (one reserved XCD) beside the sweep of block k (the other 7)
+  hipStream_t ov_chain = nullptr, ov_sweep = nullptr;
+  hipEvent_t ev_ov_chain[2] = {nullptr, nullptr}, ev_ov_sweep[2] = {nullptr, nullptr}, ev_ov_join[3] = {nullptr, nullptr, nullptr};
   double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
   LpxCtl* h_snap = nullptr;         // 2 pinned snapshots for the batched loop (batch k+1 in flight while k is read)
@@ -182,6 +186,11 @@ static void free_state(lpx_state* s) {
   if (s->h_ctl) (void)hipHostFree(s->h_ctl);
   if (s->h_snap) (void)hipHostFree(s->h_snap);
   for (hipEvent_t e : s->ev_batch) if (e) (void)hipEventDestroy(e);
+  if (s->ov_chain) (void)hipStreamDestroy(s->ov_chain);
+  if (s->ov_sweep) (void)hipStreamDestroy(s->ov_sweep);
+  for (hipEvent_t e : s->ev_ov_chain) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_ov_sweep) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_ov_join) if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -467,7 +476,7 @@ static int ensure_block_ring(lpx_state* s) {
   if (s->R.prow) return 0;
   const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
   s->R.mp = mp;
-  const size_t K = lpxk::kBlockMax;
+  const size_t K = 2 * lpxk::kBlockMax;  // two halves: the block being decided and the one being swept
   HIP_TRY(hipMalloc((void**)&s->R.prow, K * (size_t)s->B.ld * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.col, K * (size_t)mp * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.col0, K * (size_t)mp * sizeof(double)));
@@ -477,8 +486,8 @@ static int ensure_block_ring(lpx_state* s) {
   HIP_TRY(hipMalloc((void**)&s->R.up, K * sizeof(LpxCtl)));
   HIP_TRY(hipMalloc(&s->R.chain_part_a, lpxk::kChainMaxWgs * 32));
   HIP_TRY(hipMalloc(&s->R.chain_part_b, lpxk::kChainMaxWgs * 16));
-  HIP_TRY(hipMalloc((void**)&s->R.chain_bar, 16));
-  HIP_TRY(hipMemsetAsync(s->R.chain_bar, 0, 16, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.chain_bar, 256));
+  HIP_TRY(hipMemsetAsync(s->R.chain_bar, 0, 256, s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.chain_own_col, K * (size_t)mp * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.chain_own_prow, K * (size_t)s->B.ld * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.chain_own_dvc, K * (size_t)mp * sizeof(double)));
@@ -494,6 +503,23 @@ static int ensure_block_ring(lpx_state* s) {
   HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.up, 0, K * sizeof(LpxCtl), s->stream));
   HIP_TRY(hipMemsetAsync(s->d_cand, 0, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double), s->stream));
+  return 0;
+}
+
+// The second tableau / b of the out-of-place forms (pipeline 2 of the shards, the overlapped blocked loop).
+static int ensure_spare_tableau(lpx_state* s) {
+  if (s->A2) return 0;
+  const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
+  // 4 KiB skew between the two buffers: measured 346 us vs 354 us per cfg3 update with none (the read and the
+  // write stream then do not hit the same HBM channel at the same time); profiles/r01_cu_mask.log
+  const int64_t off = env_int("LPX_A2_OFFSET", 512);  // in doubles
+  HIP_TRY(hipMalloc((void**)&s->A_base[1], (size_t)(mp * s->B.ld + off) * sizeof(double)));
+  s->A2 = s->A_base[1] + off;
+  HIP_TRY(hipMalloc((void**)&s->b_base[1], (size_t)mp * sizeof(double)));
+  s->b2 = s->b_base[1];
+  HIP_TRY(hipMemset(s->A2, 0, (size_t)(mp * s->B.ld) * sizeof(double)));
+  HIP_TRY(hipMemset(s->b2, 0, (size_t)mp * sizeof(double)));
+  HIP_TRY(hipDeviceSynchronize());
   return 0;
 }
 
@@ -514,7 +540,21 @@ static int choose_block(const lpx_state* s) {
   return std::max(1, std::min(K, (int)lpxk::kBlockMax));
 }
 
-static int launch_sweep_profiled(lpx_state* s, int K) {
+// LPX_CHAIN_TRACE=<file>: phase timestamps (100 MHz ticks) of the last k_block_chain launch (diagnostics)
+static void dump_chain_trace(lpx_state* s) {
+  if (!s->R.chain_dbg) return;
+  long long h[5 * lpxk::kBlockMax];
+  if (hipMemcpy(h, s->R.chain_dbg, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+  if (FILE* f = fopen(getenv("LPX_CHAIN_TRACE"), "w")) {
+    for (int k = 0; k < lpxk::kBlockMax; k++)
+      fprintf(f, "%d %lld %lld %lld %lld %lld\n", k, h[5 * k], h[5 * k + 1], h[5 * k + 2], h[5 * k + 3], h[5 * k + 4]);
+    fclose(f);
+  }
+}
+
+// B / R: destination buffers and the ring half of the block; A_src / b_src != NULL: out of place
+static int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers& B, const lpxk::BlockRing& R,
+                                 const double* A_src, const double* b_src) {
   const bool sample = s->prof > 0 && (s->prof_seq++ % s->prof) == 0;
   if (sample) {
     if (s->ev_used + 2 > s->ev.size()) {
@@ -524,20 +564,136 @@ static int launch_sweep_profiled(lpx_state* s, int K) {
         s->ev.push_back(e);
       }
     }
-    HIP_TRY(hipEventRecord(s->ev[s->ev_used], s->stream));
+    HIP_TRY(hipEventRecord(s->ev[s->ev_used], stream));
   }
-  lpxk::launch_block_sweep(s->B, s->R, s->n, s->m, s->row0, K, env_int("LPX_SWEEP_ROWS", s->sweep_rows),
-                           s->nontemporal, s->stream);
+  lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, env_int("LPX_SWEEP_ROWS", s->sweep_rows), s->nontemporal,
+                           stream, A_src, b_src);
   if (sample) {
-    HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], s->stream));
+    HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], stream));
     s->ev_used += 2;
   }
   HIP_TRY(hipGetLastError());
   return 0;
 }
+static int launch_sweep_profiled(lpx_state* s, int K) {
+  return launch_sweep_profiled(s, K, s->stream, s->B, s->R, nullptr, nullptr);
+}
+
+// Ring half h as a ring of its own (what the sweep / fix-up kernels take).
+static lpxk::BlockRing ring_half(const lpx_state* s, int h) {
+  lpxk::BlockRing R = s->R;
+  const int64_t o = (int64_t)h * lpxk::kBlockMax;
+  R.prow += o * s->B.ld;
+  R.row0 += o * s->B.ld;
+  R.col += o * R.mp;
+  R.col0 += o * R.mp;
+  R.up += o;
+  return R;
+}
+
+// One XCD for the decisions, seven for the sweep (CU i belongs to XCD i % 8, see lpx_state_use_masked_stream).
+static int ensure_overlap_streams(lpx_state* s) {
+  if (s->ov_chain) return 0;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+  const int ncu = prop.multiProcessorCount;
+  std::vector<uint32_t> m_sweep((ncu + 31) / 32, 0u), m_chain((ncu + 31) / 32, 0u);
+  for (int cu = 0; cu < ncu; cu++) {
+    if ((cu % 8) == 7) m_chain[cu / 32] |= 1u << (cu % 32);
+    else m_sweep[cu / 32] |= 1u << (cu % 32);
+  }
+  if (env_int("LPX_OVERLAP_MASK", 1) != 0 && ncu >= 64) {
+    HIP_TRY(hipExtStreamCreateWithCUMask(&s->ov_chain, (uint32_t)m_chain.size(), m_chain.data()));
+    HIP_TRY(hipExtStreamCreateWithCUMask(&s->ov_sweep, (uint32_t)m_sweep.size(), m_sweep.data()));
+  } else {
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&s->ov_chain, hipStreamNonBlocking, hi));
+    HIP_TRY(hipStreamCreateWithFlags(&s->ov_sweep, hipStreamNonBlocking));
+  }
+  for (int k = 0; k < 2; k++) {
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_chain[k], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_sweep[k], hipEventDisableTiming));
+  }
+  for (int k = 0; k < 3; k++) HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_join[k], hipEventDisableTiming));
+  return 0;
+}
+
+// The blocked loop with the decisions one block ahead of the sweeps.  Block k's decisions (k_block_chain) read
+// the tableau as it was BEFORE block k-1's sweep and see that block's pivots as pending ones, like their own; so
+// sweep k-1 (out of place, buffer (k-1)&1 -> k&1) and decisions k run side by side, on disjoint XCDs:
+//
+//     chain stream :  chain 0 | chain 1 | chain 2 | ...          chain k   waits for sweep k-2 (its input, and the
+//     sweep stream :          | sweep 0 | sweep 1 | ...                     ring half it overwrites)
+//                                                                sweep k   waits for chain k (and follows sweep k-1)
+// Same arithmetic, same order, per tableau entry: bit-identical to the serial forms.
+static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
+  if (int rc = ensure_block_ring(s)) return rc;
+  if (int rc = ensure_spare_tableau(s)) return rc;
+  if (int rc = ensure_overlap_streams(s)) return rc;
+  launch_seed_entering(s);
+  HIP_TRY(hipEventRecord(s->ev_ov_join[0], s->stream));
+  HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_join[0], 0));
+  HIP_TRY(hipStreamWaitEvent(s->ov_sweep, s->ev_ov_join[0], 0));
+  LpxCtl* h2 = s->h_snap;
+  LpxCtl* d_snap = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&d_snap, s->h_snap, 0));
+  const int chain_wgs = env_int("LPX_CHAIN_WGS", 0);
+  double* Abuf[2] = {s->B.A, s->A2};
+  double* bbuf[2] = {s->B.b, s->b2};
+  int64_t decided = 0;
+  int nb_prev = 0, nblk = 0;
+  auto issue_block = [&](int k) -> int {  // 1: the budget is spent, nothing issued
+    int nb = K;
+    if (max_pivots >= 0) nb = (int)std::max<int64_t>(0, std::min<int64_t>(nb, max_pivots + 1 - decided));
+    if (nb <= 0) return 1;
+    const int h = k & 1;
+    if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h], 0));  // sweep k-2
+    Buffers Brd = s->B;
+    Brd.A = Abuf[k == 0 ? 0 : (k - 1) & 1];
+    Brd.b = bbuf[k == 0 ? 0 : (k - 1) & 1];
+    lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0, s->chain_seq++,
+                             s->pricing == 1, chain_wgs, d_snap + h, s->ov_chain);
+    HIP_TRY(hipEventRecord(s->ev_ov_chain[h], s->ov_chain));
+    HIP_TRY(hipStreamWaitEvent(s->ov_sweep, s->ev_ov_chain[h], 0));
+    Buffers Bdst = s->B;
+    Bdst.A = Abuf[h ^ 1];
+    Bdst.b = bbuf[h ^ 1];
+    if (int rc = launch_sweep_profiled(s, nb, s->ov_sweep, Bdst, ring_half(s, h), Abuf[h], bbuf[h])) return rc;
+    HIP_TRY(hipEventRecord(s->ev_ov_sweep[h], s->ov_sweep));
+    decided += nb;
+    nb_prev = nb;
+    nblk = k + 1;
+    return 0;
+  };
+  int rc = issue_block(0);
+  if (rc == 1) rc = 0;  // max_pivots < 0 never gets here; a zero budget issues one probing decision, so neither does 0
+  for (int k = 1; rc == 0; k++) {
+    const int r = issue_block(k);
+    if (r != 0 && r != 1) { rc = r; break; }
+    hipError_t e = hipEventSynchronize(s->ev_ov_chain[(k - 1) & 1]);
+    if (e != hipSuccess) { rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e)); break; }
+    if (h2[(k - 1) & 1].status != lpxk::kRunning || r == 1) break;
+  }
+  // join: the caller's stream continues after both; the result lives in buffer nblk & 1
+  (void)hipEventRecord(s->ev_ov_join[1], s->ov_chain);
+  (void)hipEventRecord(s->ev_ov_join[2], s->ov_sweep);
+  (void)hipStreamWaitEvent(s->stream, s->ev_ov_join[1], 0);
+  (void)hipStreamWaitEvent(s->stream, s->ev_ov_join[2], 0);
+  if (nblk & 1) {  // the two allocations swap roles (both are the state's own; freed through A_base / b_base)
+    std::swap(s->B.A, s->A2);
+    std::swap(s->B.b, s->b2);
+  }
+  hipError_t e2 = hipStreamSynchronize(s->stream);
+  if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
+  if (rc == 0) dump_chain_trace(s);
+  return rc;
+}
 
 // LPSolver.simplex's loop with K pivot decisions per pass over the tableau (bit-identical results).
 static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
+  if (env_int("LPX_CHAIN", 1) != 0 && env_int("LPX_OVERLAP", 1) != 0 && s->row0 == 0 && s->m == s->m_global)
+    return blocked_loop_overlapped(s, K, max_pivots);
   if (int rc = ensure_block_ring(s)) return rc;
   launch_seed_entering(s);
   hipEvent_t* evs = s->ev_batch;
@@ -552,7 +708,8 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
     int nb = K;
     if (max_pivots >= 0) nb = (int)std::max<int64_t>(0, std::min<int64_t>(nb, max_pivots + 1 - decided));
     if (fused && nb > 0) {
-      lpxk::launch_block_chain(s->B, s->R, s->n, s->m, nb, s->pricing == 1, chain_wgs, d_snap + slot, s->stream);
+      lpxk::launch_block_chain(s->B, s->R, s->n, s->m, nb, 0, 0, 0, 1, s->chain_seq++, s->pricing == 1, chain_wgs,
+                               d_snap + slot, s->stream);
     } else {
       for (int k = 0; k < nb; k++) {
         lpxk::launch_block_peek(s->B, s->R, s->n, s->m, s->row0, k, s->d_cand, s->stream);
@@ -581,16 +738,7 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   }
   hipError_t e2 = hipStreamSynchronize(s->stream);
   if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
-  if (rc == 0 && s->R.chain_dbg) {  // LPX_CHAIN_TRACE=<file>: phase timestamps (100 MHz ticks) of the last block
-    long long h[5 * lpxk::kBlockMax];
-    if (hipMemcpy(h, s->R.chain_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-      if (FILE* f = fopen(getenv("LPX_CHAIN_TRACE"), "w")) {
-        for (int k = 0; k < lpxk::kBlockMax; k++)
-          fprintf(f, "%d %lld %lld %lld %lld %lld\n", k, h[5 * k], h[5 * k + 1], h[5 * k + 2], h[5 * k + 3], h[5 * k + 4]);
-        fclose(f);
-      }
-    }
-  }
+  if (rc == 0) dump_chain_trace(s);
   return rc;
 }
 
@@ -781,18 +929,8 @@ static Buffers slot_buffers(lpx_state* s, int k) {
 extern "C" int lpx_shard_set_pipeline(lpx_state* s, int32_t mode) {
   if (!s || (mode != 1 && mode != 2)) return fail(LPX_BAD_ARGUMENT, "lpx_shard_set_pipeline: mode must be 1 or 2");
   HIP_TRY(hipSetDevice(s->device));
-  if (mode == 2 && !s->A2) {
-    const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
-    // 4 KiB skew between the two buffers: measured 346 us vs 354 us per cfg3 update with none (the read and the
-    // write stream then do not hit the same HBM channel at the same time); profiles/r01_cu_mask.log
-    const int64_t off = env_int("LPX_A2_OFFSET", 512);  // in doubles
-    HIP_TRY(hipMalloc((void**)&s->A_base[1], (size_t)(mp * s->B.ld + off) * sizeof(double)));
-    s->A2 = s->A_base[1] + off;
-    HIP_TRY(hipMalloc((void**)&s->b_base[1], (size_t)mp * sizeof(double)));
-    s->b2 = s->b_base[1];
-    HIP_TRY(hipMemset(s->A2, 0, (size_t)(mp * s->B.ld) * sizeof(double)));
-    HIP_TRY(hipMemset(s->b2, 0, (size_t)mp * sizeof(double)));
-    HIP_TRY(hipDeviceSynchronize());
+  if (mode == 2) {
+    if (int rc = ensure_spare_tableau(s)) return rc;
   }
   s->pipeline = mode;
   return 0;

@@ -81,7 +81,7 @@ void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* p
                  double* col_next, const LpxCtl* pend, double* d_candidate, hipStream_t s);
 // blocked pivoting: ring of pending pivots (see lpx_kernels.hip "blocked pivoting")
 constexpr int kBlockMax = 32;
-struct BlockRing {
+struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per block in flight
   double* prow;   // kBlockMax x ld : normalised pivot row of pending pivot s
   double* col;    // kBlockMax x mp : column e_s of the tableau just before pivot s
   double* col0;   // kBlockMax x mp : the same column as it stands in the stale tableau (for the fix-up)
@@ -91,7 +91,7 @@ struct BlockRing {
   // scratch of k_block_chain (single-shard blocks decided in one persistent launch)
   void* chain_part_a;      // kChainMaxWgs x 32 B
   void* chain_part_b;      // kChainMaxWgs x 16 B
-  unsigned* chain_bar;     // 16 B, zeroed before every launch
+  unsigned* chain_bar;     // 2 counters, 128 B apart; a launch zeroes the next one's
   double* chain_own_col;   // kBlockMax x mp: copy of `col` that only its writer re-reads (plain, cache-resident)
   double* chain_own_prow;  // kBlockMax x ld: likewise for `prow`
   double* chain_own_dvc;   // kBlockMax x mp: column e_s of the tableau just AFTER pivot s (restart point)
@@ -104,13 +104,17 @@ void launch_block_peek(const Buffers& B, const BlockRing& R, int n, int m_local,
                        hipStream_t s);
 void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_global, const double* d_gathered, int nranks,
                          int slot, hipStream_t s);
-// all nb decisions of a block in one persistent launch (single shard: row0 == 0, m == m_global); wgs <= 0: auto
-// host_snap: device-visible pointer to a pinned host LpxCtl that receives the loop state when the launch ends
-void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int dantzig, int wgs,
-                        LpxCtl* host_snap, hipStream_t s);
+// all nb decisions of a block in one persistent launch (single shard: row0 == 0, m == m_global); wgs <= 0: auto.
+// The rings hold 2*kBlockMax slots: `half` is the block's, `old_half` that of the previous block when its sweep has
+// not yet reached the tableau (B.A, B.b) this launch reads (n_old pivots; 0: none).  b_from_tableau: first launch
+// of a loop.  seq: launch counter (the two barrier counters alternate).  host_snap: device-visible pointer to a
+// pinned host LpxCtl that receives the loop state when the launch ends.
+void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
+                        int b_from_tableau, int seq, int dantzig, int wgs, LpxCtl* host_snap, hipStream_t s);
 // apply the valid leading pending pivots (at most K) in one pass
+// A_src / b_src != NULL: out of place — read the tableau and b there, write the updated ones to B.A / B.b
 void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
-                        bool nt, hipStream_t s);
+                        bool nt, hipStream_t s, const double* A_src = nullptr, const double* b_src = nullptr);
 // phase 1 / restore helpers
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
 void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);

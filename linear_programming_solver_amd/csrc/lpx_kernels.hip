@@ -832,19 +832,41 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
   return *sh_fail == 0;
 }
 
-// One pending pivot r applied to the entering-column value of row i (phase A) / to the row value of column j
-// (phase B).  `on` is wave-uniform: steps outside (restart, s) leave the value alone.
-#define LPX_CHAIN_STEP_A(r, on, cs_r, pe_r, l_r)                                   \
+// One pending pivot applied to the entering-column value of row i (phase A) / to the row value of column j
+// (phase B).  `on` is wave-uniform: steps outside the live range leave the value alone.
+#define LPX_CHAIN_STEP_A(on, cs_r, pe_r, l_r)                                      \
   {                                                                                \
     const double t_ = __dsub_rn(a, __dmul_rn((cs_r), (pe_r)));                     \
     const double nv_ = (i == (l_r)) ? (pe_r) : t_;                                 \
     a = (on) ? nv_ : a;                                                            \
   }
-#define LPX_CHAIN_STEP_B(r, on, cs_r, prv_r, e_r, dv_r)                            \
+#define LPX_CHAIN_STEP_B(on, cs_r, prv_r, e_r, dv_r)                               \
   {                                                                                \
     const double t_ = __dsub_rn(x, __dmul_rn((cs_r), (prv_r)));                    \
     const double nv_ = (j == (e_r)) ? (dv_r) : t_;                                 \
     x = (on) ? nv_ : x;                                                            \
+  }
+// eight consecutive steps [r0, r0+8) of one half (LDS offset `off`: 0 = previous block, kMaxBlock = this block),
+// live range [first, last); the chunk's parameters are read first, then the arithmetic (the LDS latencies overlap)
+#define LPX_CHAIN_CHUNK_A(off, r0, first, last, csv)                                                   \
+  if ((r0) < (last) && (r0) + 8 > (first)) {                                                           \
+    double pe8[8];                                                                                     \
+    int l8[8];                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) { pe8[q] = sh_pe[(off) + (r0) + q]; l8[q] = sh_l[(off) + (r0) + q]; } \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                      \
+        LPX_CHAIN_STEP_A(((r0) + q >= (first) && (r0) + q < (last)), csv[(r0) + q], pe8[q], l8[q])     \
+  }
+#define LPX_CHAIN_CHUNK_B(off, r0, first, last, prvv)                                                  \
+  if ((r0) < (last) && (r0) + 8 > (first)) {                                                           \
+    double cs8[8], dv8[8];                                                                             \
+    int e8[8];                                                                                         \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                    \
+      cs8[q] = sh_cs[(off) + (r0) + q]; dv8[q] = sh_dv[(off) + (r0) + q]; e8[q] = sh_e[(off) + (r0) + q]; \
+    }                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                      \
+        LPX_CHAIN_STEP_B(((r0) + q >= (first) && (r0) + q < (last)), cs8[q], prvv[(r0) + q], e8[q], dv8[q]) \
   }
 
 // The host's view of the loop (status, pivots, ...) goes straight into its pinned snapshot: no copy-engine
@@ -855,26 +877,59 @@ __device__ __forceinline__ void chain_publish(const LpxCtl* ctl, LpxCtl* host_sn
   __threadfence_system();
 }
 
-__global__ __launch_bounds__(256) void k_block_chain(const double* __restrict__ A, int64_t ld, int n, int m,
-                                                     const double* __restrict__ b, double* c, double* prow_ring,
-                                                     double* col_ring, double* col0_ring, double* row0_ring,
-                                                     int64_t mp, LpxCtl* ring, int nb, int32_t* perm, LpxCtl* ctl,
-                                                     ChainPart* partA, RatioRow* partB, unsigned* bar, int dantzig,
-                                                     int fences, double* own_col, double* own_prow, double* own_dvc,
-                                                     double* own_b, LpxCtl* host_snap, long long* dbg) {
+// Launch parameters.  "own" = the ring half of the block being decided (written here), "old" = the half of the
+// PREVIOUS block when its sweep has not been applied to the tableau this launch reads (n_old pivots; 0 = none):
+// the decisions then see the tableau through n_old + s pending pivots, and that sweep can run beside this launch.
+struct ChainArgs {
+  const double* A;   // tableau version read (never written during the launch)
+  const double* b;
+  int64_t ld, mp;
+  int n, m;
+  double* c;
+  int32_t* perm;
+  LpxCtl* ctl;
+  double *prow, *col, *col0, *row0, *own_col, *own_prow, *own_dvc;  // own half (slot s of the block)
+  LpxCtl* up;
+  const double *prow_o, *col_o, *own_col_o, *own_prow_o, *own_dvc_o;  // old half
+  const LpxCtl* up_o;
+  int n_old;
+  double* own_b;        // b with every decided pivot applied (kept across the launches of one loop)
+  int b_from_tableau;   // 1: first launch of a loop, own_b is not valid before decision 0
+  int nb;
+  ChainPart* partA;
+  RatioRow* partB;
+  unsigned* bar;        // this launch's barrier counter (zero on entry)
+  unsigned* bar_next;   // the next launch's: zeroed here
+  int dantzig, fences;
+  LpxCtl* host_snap;
+  long long* dbg;
+};
+
+__global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
+  constexpr int KB = kMaxBlock;  // LDS layout of the per-pivot parameters: [0, KB) old half, [KB, 2 KB) own half
   __shared__ RatioRow sh_rr[4];
-  __shared__ double sh_pe[kMaxBlock], sh_cs[kMaxBlock], sh_dv[kMaxBlock], sh_p[kMaxBlock], sh_bl[kMaxBlock], sh_win[2];
-  __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
+  __shared__ double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB], sh_win[2];
+  __shared__ int sh_e[2 * KB], sh_l[2 * KB];
   __shared__ int sh_fail, sh_restart;
+  const double* __restrict__ A = P.A;
+  const double* __restrict__ b = P.b;
+  const int64_t ld = P.ld, mp = P.mp;
+  const int n = P.n, m = P.m, nb = P.nb, n_old = P.n_old;
+  LpxCtl* const ctl = P.ctl;
   const int G = gridDim.x, T = G * 256, tid = threadIdx.x, gid = blockIdx.x * 256 + tid;
   const bool lead = gid == 0;
   if (tid == 0) sh_fail = 0;
+  if (lead) st_agent(reinterpret_cast<int32_t*>(P.bar_next), 0);
   // loop state at entry: written by earlier launches, identical in every workgroup
   int e = ctl->e_next;
   if (ctl->status != kRunning || e < 0 || nb < 1) {
-    if (lead && nb >= 1) ring[0].do_update = 0;
-    if (lead) chain_publish(ctl, host_snap);
+    if (lead && nb >= 1) P.up[0].do_update = 0;
+    if (lead) chain_publish(ctl, P.host_snap);
     return;
+  }
+  if (tid < n_old) {
+    const LpxCtl& q = P.up_o[tid];
+    sh_e[tid] = q.e_cur; sh_l[tid] = q.l; sh_p[tid] = q.p; sh_bl[tid] = q.bl;
   }
   int64_t pivots = ctl->pivots;
   const int64_t max_pivots = ctl->max_pivots;
@@ -884,50 +939,56 @@ __global__ __launch_bounds__(256) void k_block_chain(const double* __restrict__ 
 
   for (int s = 0; s < nb; ++s) {
     // ------------------------------------------------------------------ phase A: column e, ratio test
-    // Column e of the tableau with the s pending pivots applied = the stale column run through pivots 0..s-1 in
-    // order.  If an earlier pivot r* of this block entered at the same slot, its update REPLACED the column by
-    // -(col/p) (1/p in its own row) whatever it was before: the chain restarts there, from own_dvc[r*], and
-    // only pivots r* < r < s remain — so every step has the one generic form and the loop is branch-free.
-    // b needs no chain at all: own_b holds it with all pending pivots applied (one step added per decision).
-    if (dbg && lead) dbg[s * 5 + 0] = wall_clock64();
-    const double pc = ld_agent(&c[e]);  // c[e] is rewritten only in phase B, after the next barrier
+    // Column e of the current tableau = the stale column run through the pending pivots in order (old half, then
+    // this block's 0..s-1).  If a pending pivot u* entered at the same slot, its update REPLACED the column by
+    // -(col/p) (1/p in its own row) whatever it was before: the chain restarts there, from own_dvc[u*], and only
+    // the pivots after u* remain — every step has the one generic form and the loop is branch-free.
+    // b needs no chain at all: own_b holds it with every decided pivot applied (one step added per decision).
+    if (P.dbg && lead) P.dbg[s * 5 + 0] = wall_clock64();
+    const double pc = ld_agent(&P.c[e]);  // c[e] is rewritten only in phase B, after the next barrier
     if (tid < 64) {
+      const int r = tid & (KB - 1);
+      const bool old = tid < KB;
+      const bool valid = old ? r < n_old : r < s;
       bool same = false;
-      if (tid < s) {
-        sh_pe[tid] = ld_agent(&prow_ring[(int64_t)tid * ld + e]);  // one wave per workgroup, not every thread
+      if (valid) {  // one wave per workgroup fetches prow_u[e] of every pending pivot u
+        sh_pe[tid] = ld_agent((old ? P.prow_o : P.prow) + (int64_t)r * ld + e);
         same = sh_e[tid] == e;
       }
       const unsigned long long mask = __ballot(same);
       if (tid == 0) sh_restart = mask ? 63 - __clzll((long long)mask) : -1;
     }
     __syncthreads();
-    const int ra = sh_restart;
+    const int ra = sh_restart;                                   // LDS index of the restart pivot, -1: none
+    const int fo_a = ra < 0 ? 0 : (ra < KB ? ra + 1 : n_old);    // first live step of the old half
+    const int fn_a = ra >= KB ? ra - KB + 1 : 0;                 // first live step of this block's half
+    const bool use_b = P.b_from_tableau && s == 0;
     RatioRow best = rr_none();
     double best_a = 0.0, best_b = 0.0;
     for (int i = gid; i < m; i += T) {
-      const double a_stale = A[(int64_t)i * ld + e];
-      const double* src_a = (ra >= 0) ? &own_dvc[(int64_t)ra * mp + i] : &A[(int64_t)i * ld + e];
-      const double* src_b = (s > 0) ? &own_b[i] : &b[i];
+      const double* src_a = ra < 0 ? &A[(int64_t)i * ld + e]
+                                   : (ra < KB ? &P.own_dvc_o[(int64_t)ra * mp + i] : &P.own_dvc[(int64_t)(ra - KB) * mp + i]);
+      const double* src_b = use_b ? &b[i] : &P.own_b[i];
       double a = *src_a;
       const double bi = *src_b;
-      double cs[kMaxBlock];  // this thread's own stores; no branch around a load (slots >= s re-read slot 0, unused)
+      double cs[KB];  // this thread's own stores; no branch around a load (slots >= s re-read slot 0, unused)
 #pragma unroll
-      for (int q = 0; q < kMaxBlock; ++q) cs[q] = own_col[(int64_t)((q < s) ? q : 0) * mp + i];
-      st_agent(&col0_ring[(int64_t)s * mp + i], a_stale);  // the stale column, kept for k_block_fixup
+      for (int q = 0; q < KB; ++q) cs[q] = P.own_col[(int64_t)((q < s) ? q : 0) * mp + i];
+      if (fo_a < n_old) {  // uniform: pending pivots of the previous block
+        double cso[KB];
 #pragma unroll
-      for (int r0 = 0; r0 < kMaxBlock; r0 += 8) {
-        if (r0 < s && r0 + 8 > ra + 1) {  // uniform: the chunk meets (ra, s)
-          double pe8[8];  // the chunk's parameters first, then the arithmetic: the LDS latencies overlap
-          int l8[8];
+        for (int q = 0; q < KB; ++q) cso[q] = P.own_col_o[(int64_t)((q < n_old) ? q : 0) * mp + i];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) { pe8[q] = sh_pe[r0 + q]; l8[q] = sh_l[r0 + q]; }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) LPX_CHAIN_STEP_A(r0 + q, (r0 + q > ra && r0 + q < s), cs[r0 + q], pe8[q], l8[q])
-        }
+        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_A(0, r0, fo_a, n_old, cso)
       }
-      st_agent(&col_ring[(int64_t)s * mp + i], a);
-      own_col[(int64_t)s * mp + i] = a;
+      // here `a` is the entry of the tableau the sweep of THIS block will read (all older pivots applied): what
+      // k_block_fixup restarts from.  (After a restart inside this block the value is not that entry, but then
+      // the fix-up's own chain replaces it at the same pivot, whatever it starts from.)
+      st_agent(&P.col0[(int64_t)s * mp + i], a);
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_A(KB, r0, fn_a, s, cs)
+      st_agent(&P.col[(int64_t)s * mp + i], a);
+      P.own_col[(int64_t)s * mp + i] = a;
       const double rt = ratio_of(a, bi);
       if (rt < best.ratio) {  // i ascends per thread: strict < keeps the lowest row among equal ratios
         best = RatioRow{rt, i, 0};
@@ -940,56 +1001,62 @@ __global__ __launch_bounds__(256) void k_block_chain(const double* __restrict__ 
       if (w.row != INT_MAX && best.row == w.row) { sh_win[0] = best_a; sh_win[1] = best_b; }
       __syncthreads();
       if (tid == 0) {
-        ChainPart* rec = &partA[blockIdx.x];
+        ChainPart* rec = &P.partA[blockIdx.x];
         st_agent(&rec->ratio, w.ratio);
         st_agent(&rec->row, w.row);
         st_agent(&rec->a, (w.row != INT_MAX) ? sh_win[0] : 0.0);
         st_agent(&rec->bi, (w.row != INT_MAX) ? sh_win[1] : 0.0);
       }
     }
-    if (dbg && lead) dbg[s * 5 + 1] = wall_clock64();
+    if (P.dbg && lead) P.dbg[s * 5 + 1] = wall_clock64();
     target += (unsigned)G;
-    if (!grid_barrier(bar, target, &sh_fail, fences)) { if (lead) { ctl->status = 7 /* LPX_DEVICE_ERROR */; chain_publish(ctl, host_snap); } return; }
-    if (dbg && lead) dbg[s * 5 + 2] = wall_clock64();
+    if (!grid_barrier(P.bar, target, &sh_fail, P.fences)) {
+      if (lead) { ctl->status = 7 /* LPX_DEVICE_ERROR */; chain_publish(ctl, P.host_snap); }
+      return;
+    }
+    if (P.dbg && lead) P.dbg[s * 5 + 2] = wall_clock64();
 
     // ------------------------------------------------------------------ phase B: the leaving row
     RatioRow mine = rr_none();
     double mine_a = 0.0, mine_b = 0.0;
     if (tid < G) {
-      mine.ratio = ld_agent(&partA[tid].ratio);
-      mine.row = ld_agent(&partA[tid].row);
-      mine_a = ld_agent(&partA[tid].a);
-      mine_b = ld_agent(&partA[tid].bi);
+      mine.ratio = ld_agent(&P.partA[tid].ratio);
+      mine.row = ld_agent(&P.partA[tid].row);
+      mine_a = ld_agent(&P.partA[tid].a);
+      mine_b = ld_agent(&P.partA[tid].bi);
     }
     const RatioRow w = rr_block_min(mine, sh_rr);
     if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
     __syncthreads();
     if (w.row == INT_MAX || !(w.ratio < kInf)) {  // getLeaving() == -1: unbounded
       if (lead) {
-        ctl->status = 1; ctl->do_update = 0; ctl->l = -1; ctl->ratio = w.ratio; ring[s].do_update = 0;
-        chain_publish(ctl, host_snap);
+        ctl->status = 1; ctl->do_update = 0; ctl->l = -1; ctl->ratio = w.ratio; P.up[s].do_update = 0;
+        chain_publish(ctl, P.host_snap);
       }
       return;
     }
     if (max_pivots >= 0 && pivots >= max_pivots) {
       if (lead) {
-        ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; ring[s].do_update = 0;
-        chain_publish(ctl, host_snap);
+        ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; P.up[s].do_update = 0;
+        chain_publish(ctl, P.host_snap);
       }
       return;
     }
     const int l = w.row;
     const double p = sh_win[0], raw_b = sh_win[1];
     if (p == 0.0) {  // ArithmeticException in the reference, LPState.java:139
-      if (lead) { ctl->status = 8; ctl->do_update = 0; ring[s].do_update = 0; chain_publish(ctl, host_snap); }
+      if (lead) { ctl->status = 8; ctl->do_update = 0; P.up[s].do_update = 0; chain_publish(ctl, P.host_snap); }
       return;
     }
-    // Row l with the s pending pivots applied; an earlier pivot r* with the same leaving row REPLACED the row by
-    // its normalised row: restart there (own_prow[r*]).  Column e_r of the row becomes -(col_r[l]/p_r) at pivot r.
+    // Row l of the current tableau likewise; a pending pivot u* with the same leaving row REPLACED the row by its
+    // normalised row: restart there (own_prow[u*]).  Column e_u of the row becomes -(col_u[l]/p_u) at pivot u.
     if (tid < 64) {
+      const int r = tid & (KB - 1);
+      const bool old = tid < KB;
+      const bool valid = old ? r < n_old : r < s;
       bool same = false;
-      if (tid < s) {
-        const double csv = ld_agent(&col_ring[(int64_t)tid * mp + l]);
+      if (valid) {
+        const double csv = ld_agent((old ? P.col_o : P.col) + (int64_t)r * mp + l);
         sh_cs[tid] = csv;
         sh_dv[tid] = -__ddiv_rn(csv, sh_p[tid]);
         same = sh_l[tid] == l;
@@ -999,43 +1066,41 @@ __global__ __launch_bounds__(256) void k_block_chain(const double* __restrict__ 
     }
     __syncthreads();
     const int rb = sh_restart;
+    const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
+    const int fn_b = rb >= KB ? rb - KB + 1 : 0;
     const double bl = __ddiv_rn(raw_b, p);                                         // :146
     const double inv_p = __ddiv_rn(1.0, p);                                        // :139
     // the row owners add pivot s to their two running columns: the entering column after the pivot (what a later
     // decision restarts from) and b
     for (int i = gid; i < m; i += T) {
-      const double colv = own_col[(int64_t)s * mp + i];
-      const double* src_b = (s > 0) ? &own_b[i] : &b[i];
+      const double colv = P.own_col[(int64_t)s * mp + i];
+      const double* src_b = use_b ? &b[i] : &P.own_b[i];
       const double bcur = *src_b;
-      own_dvc[(int64_t)s * mp + i] = (i == l) ? inv_p : -__ddiv_rn(colv, p);      // :157 / :139
-      own_b[i] = (i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));            // :146 / :164
+      P.own_dvc[(int64_t)s * mp + i] = (i == l) ? inv_p : -__ddiv_rn(colv, p);    // :157 / :139
+      P.own_b[i] = (i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));          // :146 / :164
     }
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
     const double* rowl = A + (int64_t)l * ld;
     for (int j = gid; j < (int)ld; j += T) {
       double x = 0.0;
-      const double cj = ld_agent(&c[j]);  // this thread's own store (or the initial value)
+      const double cj = ld_agent(&P.c[j]);  // this thread's own store (or the initial value)
       if (j < n) {
-        const double x_stale = rowl[j];
-        const double* src_x = (rb >= 0) ? &own_prow[(int64_t)rb * ld + j] : &rowl[j];
+        const double* src_x = rb < 0 ? &rowl[j]
+                                     : (rb < KB ? &P.own_prow_o[(int64_t)rb * ld + j] : &P.own_prow[(int64_t)(rb - KB) * ld + j]);
         x = *src_x;
-        double prv[kMaxBlock];  // this thread's own stores
+        double prv[KB];  // this thread's own stores
 #pragma unroll
-        for (int q = 0; q < kMaxBlock; ++q) prv[q] = own_prow[(int64_t)((q < s) ? q : 0) * ld + j];
-        st_agent(&row0_ring[(int64_t)s * ld + j], x_stale);  // the stale row, kept for k_block_fixup
+        for (int q = 0; q < KB; ++q) prv[q] = P.own_prow[(int64_t)((q < s) ? q : 0) * ld + j];
+        if (fo_b < n_old) {
+          double prvo[KB];
 #pragma unroll
-        for (int r0 = 0; r0 < kMaxBlock; r0 += 8) {
-          if (r0 < s && r0 + 8 > rb + 1) {
-            double cs8[8], dv8[8];
-            int e8[8];
+          for (int q = 0; q < KB; ++q) prvo[q] = P.own_prow_o[(int64_t)((q < n_old) ? q : 0) * ld + j];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { cs8[q] = sh_cs[r0 + q]; dv8[q] = sh_dv[r0 + q]; e8[q] = sh_e[r0 + q]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-              LPX_CHAIN_STEP_B(r0 + q, (r0 + q > rb && r0 + q < s), cs8[q], prv[r0 + q], e8[q], dv8[q])
-          }
+          for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(0, r0, fo_b, n_old, prvo)
         }
+        st_agent(&P.row0[(int64_t)s * ld + j], x);  // the row as the sweep of this block will read it (see col0)
+#pragma unroll
+        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(KB, r0, fn_b, s, prv)
       }
       double cn, pr;
       if (j == e) {
@@ -1045,41 +1110,44 @@ __global__ __launch_bounds__(256) void k_block_chain(const double* __restrict__ 
         pr = __ddiv_rn(x, p);                                                      // :144
         cn = __dsub_rn(cj, __dmul_rn(pc, pr));                                     // :177
       }
-      st_agent(&prow_ring[(int64_t)s * ld + j], pr);
-      own_prow[(int64_t)s * ld + j] = pr;
-      st_agent(&c[j], cn);
+      st_agent(&P.prow[(int64_t)s * ld + j], pr);
+      P.own_prow[(int64_t)s * ld + j] = pr;
+      st_agent(&P.c[j], cn);
       if (j < n && cn > kEps) {
-        const RatioRow k2{dantzig ? -cn : 0.0, j, 0};
+        const RatioRow k2{P.dantzig ? -cn : 0.0, j, 0};
         cand = rr_min(cand, k2);
       }
     }
     {
       const RatioRow w2 = rr_block_min(cand, sh_rr);
       if (tid == 0) {
-        st_agent(&partB[blockIdx.x].ratio, w2.ratio);
-        st_agent(&partB[blockIdx.x].row, w2.row);
-        sh_e[s] = e; sh_l[s] = l; sh_p[s] = p; sh_bl[s] = bl;
+        st_agent(&P.partB[blockIdx.x].ratio, w2.ratio);
+        st_agent(&P.partB[blockIdx.x].row, w2.row);
+        sh_e[KB + s] = e; sh_l[KB + s] = l; sh_p[KB + s] = p; sh_bl[KB + s] = bl;
       }
     }
     if (lead) {
       v = __dadd_rn(v, __dmul_rn(bl, pc));                                         // :171
-      const int32_t perm_e = perm[e], perm_l = perm[n + l];                        // exchangeIndexes :311-320
-      perm[e] = perm_l;
-      perm[n + l] = perm_e;
+      const int32_t perm_e = P.perm[e], perm_l = P.perm[n + l];                    // exchangeIndexes :311-320
+      P.perm[e] = perm_l;
+      P.perm[n + l] = perm_e;
       if (track >= 0) {                                                            // LPSolver.java:151-155
         if (e == track) track = l + n;
         else if (l + n == track) track = e;
       }
-      LpxCtl& up = ring[s];
+      LpxCtl& up = P.up[s];
       up.p = p; up.bl = bl; up.e_cur = e; up.l = l; up.e_next = -1; up.parity = 0; up.do_update = 1;
     }
-    if (dbg && lead) dbg[s * 5 + 3] = wall_clock64();
+    if (P.dbg && lead) P.dbg[s * 5 + 3] = wall_clock64();
     target += (unsigned)G;
-    if (!grid_barrier(bar, target, &sh_fail, fences)) { if (lead) { ctl->status = 7; chain_publish(ctl, host_snap); } return; }
-    if (dbg && lead) dbg[s * 5 + 4] = wall_clock64();
+    if (!grid_barrier(P.bar, target, &sh_fail, P.fences)) {
+      if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); }
+      return;
+    }
+    if (P.dbg && lead) P.dbg[s * 5 + 4] = wall_clock64();
 
     RatioRow m2 = rr_none();
-    if (tid < G) { m2.ratio = ld_agent(&partB[tid].ratio); m2.row = ld_agent(&partB[tid].row); }
+    if (tid < G) { m2.ratio = ld_agent(&P.partB[tid].ratio); m2.row = ld_agent(&P.partB[tid].row); }
     const RatioRow w3 = rr_block_min(m2, sh_rr);
     const int e_next = (w3.row == INT_MAX) ? -1 : w3.row;
     pivots += 1;
@@ -1090,11 +1158,11 @@ __global__ __launch_bounds__(256) void k_block_chain(const double* __restrict__ 
       ctl->track = track; ctl->do_update = 1;
       if (e_next < 0) {
         ctl->status = 0 /* LPX_OPTIMAL once the sweep has applied this pivot */;
-        if (s + 1 < nb) ring[s + 1].do_update = 0;  // the block ends here: the sweep counts leading valid slots
+        if (s + 1 < nb) P.up[s + 1].do_update = 0;  // the block ends here: the sweep counts leading valid slots
       }
     }
     if (e_next < 0 || s + 1 == nb) {
-      if (lead) chain_publish(ctl, host_snap);
+      if (lead) chain_publish(ctl, P.host_snap);
       return;
     }
     e = e_next;
@@ -1102,6 +1170,8 @@ __global__ __launch_bounds__(256) void k_block_chain(const double* __restrict__ 
 }
 #undef LPX_CHAIN_STEP_A
 #undef LPX_CHAIN_STEP_B
+#undef LPX_CHAIN_CHUNK_A
+#undef LPX_CHAIN_CHUNK_B
 
 // The sweep is a pure streaming kernel: x -= col_s[i] * prow_s[j] for the valid pending pivots s, in order, for
 // EVERY entry — also at the few positions where a pivot does something else (its own row becomes the normalised
@@ -1185,8 +1255,11 @@ __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], cons
   }
 }
 
-template <int K, bool NT>
-__global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, int64_t ld, int m_local,
+// OOP: read the tableau from Asrc, write the updated one to A (same traffic; lets the NEXT block's decisions read
+// the un-updated tableau while this sweep streams — see blocked_loop_overlapped in lpx_engine.cpp).
+template <int K, bool NT, bool OOP>
+__global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                      int64_t ld, int m_local,
                                                       const double* __restrict__ prow_ring,
                                                       const double* __restrict__ col_ring, int64_t mp,
                                                       const LpxCtl* __restrict__ ring, int kmax,
@@ -1202,6 +1275,8 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
   const int nrows = min(m_local, r_begin + rows_per_tile) - r_begin;
   // uniform tile base (SGPRs) + 32-bit per-lane byte offset: one VGPR per address
   char* const tile_base = reinterpret_cast<char*>(A + (int64_t)r_begin * ld + strip * 512);
+  const char* const src_base =
+      OOP ? reinterpret_cast<const char*>(Asrc + (int64_t)r_begin * ld + strip * 512) : tile_base;
   const uint32_t row_bytes = (uint32_t)ld * 8u;  // the launcher checks rows_per_tile * ld * 8 < 2^32
   const uint32_t off0 = threadIdx.x * 16u;
 
@@ -1224,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
   for (int r = 0; r < RB; ++r) {
     x[r] = d2{0.0, 0.0};
     if (fast_geom) {  // uniform
-      const d2* q = reinterpret_cast<const d2*>(tile_base + (off0 + (uint32_t)r * row_bytes));
+      const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)r * row_bytes));
       x[r] = NT ? __builtin_nontemporal_load(q) : *q;
     }
   }
@@ -1234,7 +1309,7 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
   }
   __syncthreads();  // sh_col and sh_np complete
   const int np = sh_np;
-  if (np == 0) return;
+  if (np == 0 && !OOP) return;  // out of place: the tableau still has to be carried over
 
   // Fast path, the steady state (np == K): straight-line batches without any per-lane guard, software-pipelined
   // — the next batch's loads are in flight while this one runs its 2K fp64 operations per entry.
@@ -1245,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
       const int r0 = bt * RB;
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const d2* q = reinterpret_cast<const d2*>(tile_base + (off0 + (uint32_t)(r0 + RB + r) * row_bytes));
+        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(r0 + RB + r) * row_bytes));
         xn[r] = NT ? __builtin_nontemporal_load(q) : *q;
       }
       sweep_apply<K, RB, true>(x, pr, sh_col, np, r0);
@@ -1274,7 +1349,7 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, in
     for (int r = 0; r < RB; ++r) {
       y[r] = d2{0.0, 0.0};
       if (r0 + r < nrows && act) {
-        const d2* q = reinterpret_cast<const d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
         y[r] = NT ? __builtin_nontemporal_load(q) : *q;
       }
     }
@@ -1301,20 +1376,18 @@ __device__ __forceinline__ double apply_pivot(double v, int i, int j, int l_r, i
 // After the sweep: recompute the entering columns (job 0), the pivot rows (job 1) and b (job 2) of the valid
 // pending pivots from the saved stale values.  grid = (ceil(max(m, ld)/256), K, 3).
 __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int64_t ld, int n, int m_local, int row0,
-                                                     double* __restrict__ b, const double* __restrict__ prow_ring,
+                                                     double* b, const double* __restrict__ prow_ring,
                                                      const double* __restrict__ col_ring,
                                                      const double* __restrict__ col0_ring,
                                                      const double* __restrict__ row0_ring, int64_t mp,
                                                      const LpxCtl* __restrict__ ring, int kmax,
-                                                     unsigned* chain_bar) {
+                                                     const double* b_src) {
   __shared__ double sh_p[kMaxBlock], sh_bl[kMaxBlock], sh_x[kMaxBlock];
-  if (chain_bar && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-    *chain_bar = 0;  // the next k_block_chain's grid-barrier counter
   __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
   __shared__ int sh_np;
   const int s = blockIdx.y, job = blockIdx.z;
   const int np = ring_count(ring, kMaxBlock, kmax, &sh_np);
-  if (s >= np || (job == 2 && s != 0)) return;
+  if (job == 2 ? s != 0 : s >= np) return;  // the b job also runs for an empty block (out of place: it copies b)
   if ((int)threadIdx.x < np) {
     const LpxCtl& q = ring[threadIdx.x];
     sh_e[threadIdx.x] = q.e_cur;
@@ -1347,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
     }
   } else {  // b of every local row (LPState.java:164 / :146)
     if (t < m_local) {
-      double bi = b[t];
+      double bi = b_src[t];  // == b unless the sweep ran out of place
       for (int r = 0; r < np; ++r)
         bi = (t == sh_l[r]) ? sh_bl[r] : __dsub_rn(bi, __dmul_rn(col_ring[(int64_t)r * mp + t], sh_bl[r]));
       b[t] = bi;
@@ -1572,31 +1645,46 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
                      R.prow + (int64_t)slot * B.ld, B.perm, B.ctl, R.up + slot, 0);
 }
 
-void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int dantzig, int wgs,
-                        LpxCtl* host_snap, hipStream_t s) {
+// half / old_half: which half of the 2*kBlockMax-slot rings this block / the not-yet-swept previous block uses
+// (n_old = 0: no such block, the tableau read is current); seq: launch counter of the loop (barrier counters
+// alternate); B.A / B.b: the tableau version to read.
+void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
+                        int b_from_tableau, int seq, int dantzig, int wgs, LpxCtl* host_snap, hipStream_t s) {
   static const int fences = getenv("LPX_CHAIN_FENCES") ? atoi(getenv("LPX_CHAIN_FENCES")) : 3;
   const int64_t work = std::max<int64_t>(m, B.ld);
   // two rows / columns per thread: measured best (a grid barrier costs ~1 us at 32 workgroups, ~4 us at 128)
   int G = wgs > 0 ? wgs : (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 511) / 512));
   G = std::max(1, std::min(G, kChainMaxWgs));
-  // R.chain_bar is zero here: zeroed at allocation and again by every k_block_fixup, which follows every chain
-  hipLaunchKernelGGL(k_block_chain, dim3(G), dim3(256), 0, s, B.A, B.ld, n, m, B.b, B.c, R.prow, R.col, R.col0, R.row0,
-                     R.mp, R.up, nb, B.perm, B.ctl, reinterpret_cast<ChainPart*>(R.chain_part_a),
-                     reinterpret_cast<RatioRow*>(R.chain_part_b), R.chain_bar, dantzig, fences, R.chain_own_col, R.chain_own_prow, R.chain_own_dvc,
-                     R.chain_own_b, host_snap, R.chain_dbg);
+  const int64_t K = kBlockMax;
+  ChainArgs P{};
+  P.A = B.A; P.b = B.b; P.ld = B.ld; P.mp = R.mp; P.n = n; P.m = m;
+  P.c = B.c; P.perm = B.perm; P.ctl = B.ctl;
+  const int64_t ho = half * K, oo = old_half * K;
+  P.prow = R.prow + ho * B.ld; P.col = R.col + ho * R.mp; P.col0 = R.col0 + ho * R.mp; P.row0 = R.row0 + ho * B.ld;
+  P.own_col = R.chain_own_col + ho * R.mp; P.own_prow = R.chain_own_prow + ho * B.ld;
+  P.own_dvc = R.chain_own_dvc + ho * R.mp; P.up = R.up + ho;
+  P.prow_o = R.prow + oo * B.ld; P.col_o = R.col + oo * R.mp;
+  P.own_col_o = R.chain_own_col + oo * R.mp; P.own_prow_o = R.chain_own_prow + oo * B.ld;
+  P.own_dvc_o = R.chain_own_dvc + oo * R.mp; P.up_o = R.up + oo;
+  P.n_old = n_old; P.own_b = R.chain_own_b; P.b_from_tableau = b_from_tableau; P.nb = nb;
+  P.partA = reinterpret_cast<ChainPart*>(R.chain_part_a); P.partB = reinterpret_cast<RatioRow*>(R.chain_part_b);
+  P.bar = R.chain_bar + 32 * (seq & 1); P.bar_next = R.chain_bar + 32 * ((seq + 1) & 1);
+  P.dantzig = dantzig; P.fences = fences; P.host_snap = host_snap; P.dbg = R.chain_dbg;
+  hipLaunchKernelGGL(k_block_chain, dim3(G), dim3(256), 0, s, P);
 }
 
 template <int K>
 static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_tile, bool nt,
-                           hipStream_t s) {
+                           const double* A_src, hipStream_t s) {
   const int nstrips = (int)((B.ld + 511) / 512);
   const int ntiles = (m_local + rows_per_tile - 1) / rows_per_tile;
-  if (nt)
-    hipLaunchKernelGGL((k_update_multi<K, true>), dim3(nstrips * ntiles), dim3(256), 0, s, B.A, B.ld, m_local, R.prow,
-                       R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
-  else
-    hipLaunchKernelGGL((k_update_multi<K, false>), dim3(nstrips * ntiles), dim3(256), 0, s, B.A, B.ld, m_local, R.prow,
-                       R.col, R.mp, R.up, kmax, rows_per_tile, nstrips);
+  const dim3 grid(nstrips * ntiles), block(256);
+#define LPX_LAUNCH_SWEEP(NT_, OOP_)                                                                              \
+  hipLaunchKernelGGL((k_update_multi<K, NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, \
+                     R.mp, R.up, kmax, rows_per_tile, nstrips)
+  if (A_src) { if (nt) LPX_LAUNCH_SWEEP(true, true); else LPX_LAUNCH_SWEEP(false, true); }
+  else { if (nt) LPX_LAUNCH_SWEEP(true, false); else LPX_LAUNCH_SWEEP(false, false); }
+#undef LPX_LAUNCH_SWEEP
 }
 
 // rows_per_tile <= 0: chosen here from measurements (profiles/r01_sweep_rows.txt).  Up to K = 16 the sweep is
@@ -1604,7 +1692,7 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
 // it is co-limited by the fp64 VALU, the per-workgroup prologue (2K doubles of pivot rows per thread) weighs more,
 // and 64-row tiles win (+20 % over 16) as long as the grid still has a few thousand workgroups.
 void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
-                        bool nt, hipStream_t s) {
+                        bool nt, hipStream_t s, const double* A_src, const double* b_src) {
   if (K < 1) return;
   if (rows_per_tile <= 0) {
     const int64_t nstrips = (B.ld + 511) / 512;
@@ -1617,14 +1705,14 @@ void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local
   }
   rows_per_tile = std::max(8, std::min(rows_per_tile, kSweepMaxRows)) & ~7;  // rows go four or eight at a time
   while (rows_per_tile > 8 && (int64_t)rows_per_tile * B.ld * 8 >= (int64_t)1 << 32) rows_per_tile -= 8;  // 32-bit offsets
-  if (K <= 2) launch_sweep_k<2>(B, R, m_local, K, rows_per_tile, nt, s);
-  else if (K <= 4) launch_sweep_k<4>(B, R, m_local, K, rows_per_tile, nt, s);
-  else if (K <= 8) launch_sweep_k<8>(B, R, m_local, K, rows_per_tile, nt, s);
-  else if (K <= 16) launch_sweep_k<16>(B, R, m_local, K, rows_per_tile, nt, s);
-  else launch_sweep_k<32>(B, R, m_local, K, rows_per_tile, nt, s);
+  if (K <= 2) launch_sweep_k<2>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+  else if (K <= 4) launch_sweep_k<4>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+  else if (K <= 8) launch_sweep_k<8>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+  else if (K <= 16) launch_sweep_k<16>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+  else launch_sweep_k<32>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
-                     R.col0, R.row0, R.mp, R.up, K, R.chain_bar);
+                     R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b);
 }
 
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {
