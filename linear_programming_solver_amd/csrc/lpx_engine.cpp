@@ -638,22 +638,34 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
   LpxCtl* h2 = s->h_snap;
   LpxCtl* d_snap = nullptr;
   HIP_TRY(hipHostGetDevicePointer((void**)&d_snap, s->h_snap, 0));
-  const int chain_wgs = env_int("LPX_CHAIN_WGS", 0);
+  // 32 workgroups = one per CU of the reserved XCD; more of them slow the concurrent sweep down more than they
+  // speed the decisions up (cfg4: 16 / 32 / 64 workgroups -> 14.1k / 15.0k / 14.0k pivots/s)
+  const int64_t work = std::max<int64_t>(s->m, s->B.ld);
+  const int chain_wgs = env_int("LPX_CHAIN_WGS", (int)std::min<int64_t>(32, std::max<int64_t>(1, (work + 511) / 512)));
   double* Abuf[2] = {s->B.A, s->A2};
   double* bbuf[2] = {s->B.b, s->b2};
   int64_t decided = 0;
   int nb_prev = 0, nblk = 0;
+  const bool serial = env_int("LPX_OVERLAP_SERIAL", 0) != 0;
   auto issue_block = [&](int k) -> int {  // 1: the budget is spent, nothing issued
     int nb = K;
     if (max_pivots >= 0) nb = (int)std::max<int64_t>(0, std::min<int64_t>(nb, max_pivots + 1 - decided));
     if (nb <= 0) return 1;
     const int h = k & 1;
-    if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h], 0));  // sweep k-2
     Buffers Brd = s->B;
-    Brd.A = Abuf[k == 0 ? 0 : (k - 1) & 1];
-    Brd.b = bbuf[k == 0 ? 0 : (k - 1) & 1];
-    lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0, s->chain_seq++,
-                             s->pricing == 1, chain_wgs, d_snap + h, s->ov_chain);
+    if (serial) {  // diagnostics (LPX_OVERLAP_SERIAL=1): same kernels and streams, no concurrency
+      if (k >= 1) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h ^ 1], 0));  // sweep k-1
+      Brd.A = Abuf[h];
+      Brd.b = bbuf[h];
+      lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, 0, 1, s->chain_seq++, s->pricing == 1, chain_wgs,
+                               d_snap + h, s->ov_chain);
+    } else {
+      if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h], 0));  // sweep k-2
+      Brd.A = Abuf[k == 0 ? 0 : (k - 1) & 1];
+      Brd.b = bbuf[k == 0 ? 0 : (k - 1) & 1];
+      lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0, s->chain_seq++,
+                               s->pricing == 1, chain_wgs, d_snap + h, s->ov_chain);
+    }
     HIP_TRY(hipEventRecord(s->ev_ov_chain[h], s->ov_chain));
     HIP_TRY(hipStreamWaitEvent(s->ov_sweep, s->ev_ov_chain[h], 0));
     Buffers Bdst = s->B;

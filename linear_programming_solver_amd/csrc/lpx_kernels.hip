@@ -805,6 +805,9 @@ __device__ __forceinline__ void st_agent(int32_t* p, int32_t x) {
   __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifndef LPX_BARRIER_SLEEP
+#define LPX_BARRIER_SLEEP __builtin_amdgcn_s_sleep(1)
+#endif
 // Monotonic-counter grid barrier.  Every wave drains its stores, the workgroup meets, one lane publishes with an
 // agent-scope release, arrives, polls (relaxed, bounded) and acquires; the second workgroup barrier holds the other
 // waves until the invalidate has completed.  Returns false when the spin bound was hit (never in a healthy run:
@@ -820,7 +823,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned spins = 0;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
+      LPX_BARRIER_SLEEP;
       if (++spins > (1u << 22)) { *sh_fail = 1; break; }
     }
     if (fences & 2) {
