@@ -567,11 +567,8 @@ static int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const 
     HIP_TRY(hipEventRecord(s->ev[s->ev_used], stream));
   }
   lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, env_int("LPX_SWEEP_ROWS", s->sweep_rows), s->nontemporal,
-                           stream, A_src, b_src);
-  if (sample) {
-    HIP_TRY(hipEventRecord(s->ev[s->ev_used + 1], stream));
-    s->ev_used += 2;
-  }
+                           stream, A_src, b_src, sample ? s->ev[s->ev_used + 1] : nullptr);
+  if (sample) s->ev_used += 2;
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -667,6 +664,10 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
                                s->pricing == 1, chain_wgs, d_snap + h, s->ov_chain);
     }
     HIP_TRY(hipEventRecord(s->ev_ov_chain[h], s->ov_chain));
+    if (max_pivots >= 0 && decided == max_pivots) {  // the budget is spent: this decision can only report the end
+      decided += nb;                                 // (LIMIT / UNBOUNDED), there is nothing to sweep
+      return 0;
+    }
     HIP_TRY(hipStreamWaitEvent(s->ov_sweep, s->ev_ov_chain[h], 0));
     Buffers Bdst = s->B;
     Bdst.A = Abuf[h ^ 1];

@@ -114,7 +114,8 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
 // apply the valid leading pending pivots (at most K) in one pass
 // A_src / b_src != NULL: out of place — read the tableau and b there, write the updated ones to B.A / B.b
 void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
-                        bool nt, hipStream_t s, const double* A_src = nullptr, const double* b_src = nullptr);
+                        bool nt, hipStream_t s, const double* A_src = nullptr, const double* b_src = nullptr,
+                        hipEvent_t after_sweep = nullptr);  // after_sweep: recorded between the sweep and the fix-up
 // phase 1 / restore helpers
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
 void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);

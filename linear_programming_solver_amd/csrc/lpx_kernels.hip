@@ -1695,7 +1695,7 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
 // it is co-limited by the fp64 VALU, the per-workgroup prologue (2K doubles of pivot rows per thread) weighs more,
 // and 64-row tiles win (+20 % over 16) as long as the grid still has a few thousand workgroups.
 void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
-                        bool nt, hipStream_t s, const double* A_src, const double* b_src) {
+                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep) {
   if (K < 1) return;
   if (rows_per_tile <= 0) {
     const int64_t nstrips = (B.ld + 511) / 512;
@@ -1713,6 +1713,7 @@ void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local
   else if (K <= 8) launch_sweep_k<8>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
   else if (K <= 16) launch_sweep_k<16>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
   else launch_sweep_k<32>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+  if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
                      R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b);
