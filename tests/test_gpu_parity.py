@@ -726,6 +726,47 @@ def test_blocked_pivoting_is_bit_identical(lps, oracle, shape, block):
     st.close()
 
 
+@pytest.mark.parametrize("knobs", [
+    {"LPX_OVERLAP": "0"},                              # k_block_chain, then the in-place sweep, one after the other
+    {"LPX_CHAIN": "0"},                                # three launches per decision (the form the shards use)
+    {"LPX_OVERLAP_SERIAL": "1"},                       # out-of-place sweeps without concurrency
+    {"LPX_OVERLAP_MASK": "0"},                         # decisions beside the sweep without CU masks
+    {"LPX_CHAIN_WGS": "1"}, {"LPX_CHAIN_WGS": "3"},    # several rows / columns per thread in k_block_chain
+    {"LPX_CHAIN_WGS": "7", "LPX_OVERLAP": "0"},
+], ids=lambda k: ",".join("%s=%s" % kv for kv in sorted(k.items())))
+def test_blocked_loop_forms_are_bit_identical(lps, oracle, knobs, monkeypatch):
+    """Every form of the blocked loop (default: decisions one block ahead of out-of-place sweeps) gives the
+    one-pass-per-pivot result bit for bit; the library reads these diagnostic knobs at every call."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for (m, n), block in (((300, 700), 32), ((1100, 260), 16), ((64, 2100), 8)):
+        A, b, c = dense_lp(m, n, seed=7 * m + n)
+        st = lps.LPState(A, b, c, block=block)
+        ref = oracle.State(A, b, c, kind=oracle.FP64)
+        for budget in (block, 2 * block + 3, 5 * block, 1, -1):
+            status, pivots, _ = st.simplex_loop(max_pivots=budget)
+            want = ref.simplex_loop(max_pivots=budget)
+            assert (status, pivots) == (want["status"], want["pivots"]), (knobs, m, n, block, budget)
+            assert_state_bits_equal(st.read(), ref.read(), "%s block %d budget %d" % (knobs, block, budget))
+        st.close()
+
+
+def test_blocked_loop_many_blocks_and_dantzig(lps, oracle):
+    """Long runs through the overlapped loop (many blocks in flight, both ring halves and both tableau buffers in
+    use) for both pricing rules, resumed in pieces whose lengths are not multiples of the block."""
+    m, n = 600, 900
+    A, b, c = dense_lp(m, n, seed=99)
+    for pricing, rule in ((None, 0), ("dantzig", 1)):
+        st = lps.LPState(A, b, c, block=32, **({"pricing": pricing} if pricing else {}))
+        ref = oracle.State(A, b, c, kind=oracle.FP64, pricing=rule)
+        for budget in (500, 333, 64, -1):
+            status, pivots, _ = st.simplex_loop(max_pivots=budget)
+            want = ref.simplex_loop(max_pivots=budget)
+            assert (status, pivots) == (want["status"], want["pivots"]), (pricing, budget)
+            assert_state_bits_equal(st.read(), ref.read(), "%s budget %d" % (pricing, budget))
+        st.close()
+
+
 def test_blocked_pivoting_degenerate_unbounded_and_tracking(lps, oracle):
     # ties everywhere
     m, n = 70, 40
