@@ -260,11 +260,18 @@ def main():
         elapsed = float(t.item())
     assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
     if block > 1:
-        # blocked pivoting: ceil((K+1)/block) sweeps (the last decision of a budgeted run only reports the end)
-        # (the overlapped single-GPU loop issues no sweep for that last, reporting-only decision)
+        # blocked pivoting, sharded driver: ceil((K+1)/block) sweeps (the last decision of a budgeted run only reports
+        # the end).  Single-GPU engine: blocks of `block` decisions while the budget lasts, then powers of two
+        # (lpx_engine.cpp block_len); its overlapped loop issues no sweep for the reporting-only last decision.
         expect = 0 if args.event_every <= 0 else (K + 1 + block - 1) // block
-        if not sharded and launches == (K + block - 1) // block:
-            expect = launches
+        if not sharded and args.event_every > 0:
+            decided, sweeps = 0, 0
+            while decided < K + 1:
+                room = K + 1 - decided
+                nb = block if room >= block else 1 << (room.bit_length() - 1)
+                sweeps += 1
+                decided += nb
+            expect = launches if launches in (sweeps, sweeps - 1) else sweeps
         sampled_pivots = K                      # every sweep is timed: together they applied all K pivots
     else:
         block = 1

@@ -540,6 +540,18 @@ static int choose_block(const lpx_state* s) {
   return std::max(1, std::min(K, (int)lpxk::kBlockMax));
 }
 
+// Decisions of the next block: K while the budget lasts, then powers of two, so that every sweep applies exactly
+// as many pivots as one of its template instances is built for (a partly filled instance takes the guarded path).
+static int block_len(int K, int64_t max_pivots, int64_t decided) {
+  if (max_pivots < 0) return K;
+  const int64_t room = max_pivots + 1 - decided;  // +1: the decision that reports PIVOT_LIMIT
+  if (room >= K) return K;
+  if (room <= 0) return 0;
+  int nb = 1;
+  while (2 * nb <= room) nb *= 2;
+  return nb;
+}
+
 // LPX_CHAIN_TRACE=<file>: phase timestamps (100 MHz ticks) of the last k_block_chain launch (diagnostics)
 static void dump_chain_trace(lpx_state* s) {
   if (!s->R.chain_dbg) return;
@@ -645,8 +657,7 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
   int nb_prev = 0, nblk = 0;
   const bool serial = env_int("LPX_OVERLAP_SERIAL", 0) != 0;
   auto issue_block = [&](int k) -> int {  // 1: the budget is spent, nothing issued
-    int nb = K;
-    if (max_pivots >= 0) nb = (int)std::max<int64_t>(0, std::min<int64_t>(nb, max_pivots + 1 - decided));
+    const int nb = block_len(K, max_pivots, decided);
     if (nb <= 0) return 1;
     const int h = k & 1;
     Buffers Brd = s->B;
@@ -718,8 +729,7 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   LpxCtl* d_snap = nullptr;  // the pinned snapshots as the device sees them
   if (fused) HIP_TRY(hipHostGetDevicePointer((void**)&d_snap, s->h_snap, 0));
   auto issue_block = [&](int slot) -> int {
-    int nb = K;
-    if (max_pivots >= 0) nb = (int)std::max<int64_t>(0, std::min<int64_t>(nb, max_pivots + 1 - decided));
+    const int nb = block_len(K, max_pivots, decided);
     if (fused && nb > 0) {
       lpxk::launch_block_chain(s->B, s->R, s->n, s->m, nb, 0, 0, 0, 1, s->chain_seq++, s->pricing == 1, chain_wgs,
                                d_snap + slot, s->stream);

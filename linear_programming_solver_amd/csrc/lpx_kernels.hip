@@ -851,8 +851,9 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
   }
 // eight consecutive steps [r0, r0+8) of one half (LDS offset `off`: 0 = previous block, kMaxBlock = this block),
 // live range [first, last); the chunk's parameters are read first, then the arithmetic (the LDS latencies overlap)
+#define LPX_CHAIN_LIVE(r0, first, last) ((r0) < (last) && (r0) + 8 > (first))
 #define LPX_CHAIN_CHUNK_A(off, r0, first, last, csv)                                                   \
-  if ((r0) < (last) && (r0) + 8 > (first)) {                                                           \
+  if (LPX_CHAIN_LIVE(r0, first, last)) {                                                           \
     double pe8[8];                                                                                     \
     int l8[8];                                                                                         \
     _Pragma("unroll") for (int q = 0; q < 8; ++q) { pe8[q] = sh_pe[(off) + (r0) + q]; l8[q] = sh_l[(off) + (r0) + q]; } \
@@ -861,7 +862,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
         LPX_CHAIN_STEP_A(((r0) + q >= (first) && (r0) + q < (last)), csv[(r0) + q], pe8[q], l8[q])     \
   }
 #define LPX_CHAIN_CHUNK_B(off, r0, first, last, prvv)                                                  \
-  if ((r0) < (last) && (r0) + 8 > (first)) {                                                           \
+  if (LPX_CHAIN_LIVE(r0, first, last)) {                                                           \
     double cs8[8], dv8[8];                                                                             \
     int e8[8];                                                                                         \
     _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                                    \
@@ -974,16 +975,24 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
       const double* src_b = use_b ? &b[i] : &P.own_b[i];
       double a = *src_a;
       const double bi = *src_b;
-      double cs[KB];  // this thread's own stores; no branch around a load (slots >= s re-read slot 0, unused)
+      // this thread's own stores, only the chunks with a live step (after a restart most are dead: the rings
+      // exceed the L2, every dead chunk is HBM traffic taken from the sweep running beside this launch); all
+      // loads are issued before the first use — one round trip
+      double cs[KB], cso[KB];
 #pragma unroll
-      for (int q = 0; q < KB; ++q) cs[q] = P.own_col[(int64_t)((q < s) ? q : 0) * mp + i];
-      if (fo_a < n_old) {  // uniform: pending pivots of the previous block
-        double cso[KB];
+      for (int r0 = 0; r0 < KB; r0 += 8)
+        if (LPX_CHAIN_LIVE(r0, fo_a, n_old)) {
 #pragma unroll
-        for (int q = 0; q < KB; ++q) cso[q] = P.own_col_o[(int64_t)((q < n_old) ? q : 0) * mp + i];
+          for (int q = 0; q < 8; ++q) cso[r0 + q] = P.own_col_o[(int64_t)(r0 + q) * mp + i];
+        }
 #pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_A(0, r0, fo_a, n_old, cso)
-      }
+      for (int r0 = 0; r0 < KB; r0 += 8)
+        if (LPX_CHAIN_LIVE(r0, fn_a, s)) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) cs[r0 + q] = P.own_col[(int64_t)(r0 + q) * mp + i];
+        }
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_A(0, r0, fo_a, n_old, cso)
       // here `a` is the entry of the tableau the sweep of THIS block will read (all older pivots applied): what
       // k_block_fixup restarts from.  (After a restart inside this block the value is not that entry, but then
       // the fix-up's own chain replaces it at the same pivot, whatever it starts from.)
@@ -1091,16 +1100,21 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
         const double* src_x = rb < 0 ? &rowl[j]
                                      : (rb < KB ? &P.own_prow_o[(int64_t)rb * ld + j] : &P.own_prow[(int64_t)(rb - KB) * ld + j]);
         x = *src_x;
-        double prv[KB];  // this thread's own stores
+        double prv[KB], prvo[KB];  // this thread's own stores, live chunks only (see phase A)
 #pragma unroll
-        for (int q = 0; q < KB; ++q) prv[q] = P.own_prow[(int64_t)((q < s) ? q : 0) * ld + j];
-        if (fo_b < n_old) {
-          double prvo[KB];
+        for (int r0 = 0; r0 < KB; r0 += 8)
+          if (LPX_CHAIN_LIVE(r0, fo_b, n_old)) {
 #pragma unroll
-          for (int q = 0; q < KB; ++q) prvo[q] = P.own_prow_o[(int64_t)((q < n_old) ? q : 0) * ld + j];
+            for (int q = 0; q < 8; ++q) prvo[r0 + q] = P.own_prow_o[(int64_t)(r0 + q) * ld + j];
+          }
 #pragma unroll
-          for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(0, r0, fo_b, n_old, prvo)
-        }
+        for (int r0 = 0; r0 < KB; r0 += 8)
+          if (LPX_CHAIN_LIVE(r0, fn_b, s)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) prv[r0 + q] = P.own_prow[(int64_t)(r0 + q) * ld + j];
+          }
+#pragma unroll
+        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(0, r0, fo_b, n_old, prvo)
         st_agent(&P.row0[(int64_t)s * ld + j], x);  // the row as the sweep of this block will read it (see col0)
 #pragma unroll
         for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(KB, r0, fn_b, s, prv)
@@ -1175,6 +1189,7 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
 #undef LPX_CHAIN_STEP_B
 #undef LPX_CHAIN_CHUNK_A
 #undef LPX_CHAIN_CHUNK_B
+#undef LPX_CHAIN_LIVE
 
 // The sweep is a pure streaming kernel: x -= col_s[i] * prow_s[j] for the valid pending pivots s, in order, for
 // EVERY entry — also at the few positions where a pivot does something else (its own row becomes the normalised
