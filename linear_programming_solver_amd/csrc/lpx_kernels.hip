@@ -808,8 +808,8 @@ __device__ __forceinline__ void st_agent(int32_t* p, int32_t x) {
 #ifndef LPX_BARRIER_SLEEP
 #define LPX_BARRIER_SLEEP __builtin_amdgcn_s_sleep(1)
 #endif
-// Monotonic-counter grid barrier.  Every wave drains its stores, the workgroup meets, one lane publishes with an
-// agent-scope release, arrives, polls (relaxed, bounded) and acquires; the second workgroup barrier holds the other
+// Monotonic-counter grid barrier.  Every wave drains its stores, the workgroup meets, one lane (optionally after an
+// agent-scope release) arrives, polls (relaxed, bounded) and acquires; the second workgroup barrier holds the other
 // waves until the invalidate has completed.  Returns false when the spin bound was hit (never in a healthy run:
 // it only keeps a bug from hanging the device).  fences: bit 0 = release fence, bit 1 = acquire fence.
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* sh_fail, int fences) {
@@ -1668,7 +1668,11 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 // alternate); B.A / B.b: the tableau version to read.
 void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
                         int b_from_tableau, int seq, int dantzig, int wgs, LpxCtl* host_snap, hipStream_t s) {
-  static const int fences = getenv("LPX_CHAIN_FENCES") ? atoi(getenv("LPX_CHAIN_FENCES")) : 3;
+  // 2 = acquire only: everything that crosses workgroups inside the launch is stored write-through (st_agent), every
+  // wave drains its stores (s_waitcnt vmcnt(0)) and the workgroup meets before its one lane arrives at the counter —
+  // the publish form that needs no release fence.  A release (bit 0: buffer_wbl2) costs ~2 us per barrier AND slows
+  // the sweep running beside the launch (cfg4: 1.99 -> 1.91 ms; cfg3: 39.4k -> 45.7k pivots/s without it).
+  static const int fences = getenv("LPX_CHAIN_FENCES") ? atoi(getenv("LPX_CHAIN_FENCES")) : 2;
   const int64_t work = std::max<int64_t>(m, B.ld);
   // two rows / columns per thread: measured best (a grid barrier costs ~1 us at 32 workgroups, ~4 us at 128)
   int G = wgs > 0 ? wgs : (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 511) / 512));
