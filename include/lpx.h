@@ -116,7 +116,9 @@ int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving);
  * taken from the not-yet-updated tableau (each needs one column and one row, recovered by the pending pivots'
  * rank-1 formulas) and then applied in ONE sweep that runs every entry through the K updates in order —
  * bit-identical to K separate updates, 1/K of the HBM traffic per pivot.  0 = choose by size (default),
- * 1 = off (one update pass per pivot), 2..32 = fixed. */
+ * 1 = off (one update pass per pivot), 2..32 = fixed (powers of two sweep fastest).  On an unsharded handle the
+ * K decisions are one persistent launch and run beside the previous block's sweep, which then works out of place:
+ * the handle allocates a second tableau (same size) at the first blocked loop. */
 int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep);
 /* The value in effect (after the by-size choice): 1 = one update pass per pivot, K > 1 = K pivots per sweep. */
 int lpx_state_get_block(const lpx_state* s);
