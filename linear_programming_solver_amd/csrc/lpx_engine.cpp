@@ -611,10 +611,17 @@ static int ensure_overlap_streams(lpx_state* s) {
     if ((cu % 8) == 7) m_chain[cu / 32] |= 1u << (cu % 32);
     else m_sweep[cu / 32] |= 1u << (cu % 32);
   }
+  bool masked = false;
   if (env_int("LPX_OVERLAP_MASK", 1) != 0 && ncu >= 64) {
-    HIP_TRY(hipExtStreamCreateWithCUMask(&s->ov_chain, (uint32_t)m_chain.size(), m_chain.data()));
-    HIP_TRY(hipExtStreamCreateWithCUMask(&s->ov_sweep, (uint32_t)m_sweep.size(), m_sweep.data()));
-  } else {
+    masked = hipExtStreamCreateWithCUMask(&s->ov_chain, (uint32_t)m_chain.size(), m_chain.data()) == hipSuccess &&
+             hipExtStreamCreateWithCUMask(&s->ov_sweep, (uint32_t)m_sweep.size(), m_sweep.data()) == hipSuccess;
+    if (!masked) {  // no CU masking on this runtime: plain streams below (same results, less isolation)
+      (void)hipGetLastError();
+      if (s->ov_chain) { (void)hipStreamDestroy(s->ov_chain); s->ov_chain = nullptr; }
+      if (s->ov_sweep) { (void)hipStreamDestroy(s->ov_sweep); s->ov_sweep = nullptr; }
+    }
+  }
+  if (!masked) {
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIP_TRY(hipStreamCreateWithPriority(&s->ov_chain, hipStreamNonBlocking, hi));
