@@ -1204,9 +1204,6 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
 // (cfg4: 1.36 ms for one pass, 1.55 ms at K = 16, 2.4 ms at K = 32; a one-double-per-thread variant with
 // twice the occupancy was not faster).
 constexpr int kSweepMaxRows = 128;
-#ifndef LPX_SWEEP_D
-#define LPX_SWEEP_D 2
-#endif
 
 // Number of valid leading pending pivots (slots >= kmax were not decided this block): one parallel look at the
 // ring by the first wave instead of a chain of dependent loads.  Result valid in every thread.
@@ -1230,7 +1227,7 @@ __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], cons
     // np == K: straight-line code with the LDS reads of step s+D issued before the arithmetic of step s (the
     // compiler, minimising registers, otherwise puts every read right in front of its use and the wave eats the
     // full LDS latency 2K times per batch — measured: the fp64 VALU then idles half of the time).
-    constexpr int D = LPX_SWEEP_D;  // read-ahead distance in steps
+    constexpr int D = 2;  // read-ahead distance in steps (1, 3 and 4 measured the same or worse)
     d2 cc[D + 1][RB / 2];
 #pragma unroll
     for (int s = 0; s < D && s < K; ++s)
