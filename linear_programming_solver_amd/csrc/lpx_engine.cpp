@@ -723,8 +723,15 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
 
 // LPSolver.simplex's loop with K pivot decisions per pass over the tableau (bit-identical results).
 static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
-  if (env_int("LPX_CHAIN", 1) != 0 && env_int("LPX_OVERLAP", 1) != 0 && s->row0 == 0 && s->m == s->m_global)
-    return blocked_loop_overlapped(s, K, max_pivots);
+  if (env_int("LPX_CHAIN", 1) != 0 && env_int("LPX_OVERLAP", 1) != 0 && s->row0 == 0 && s->m == s->m_global) {
+    // the overlapped form needs a second tableau: a tableau of more than half the HBM keeps the in-place form
+    if (s->A2 || ensure_spare_tableau(s) == 0) return blocked_loop_overlapped(s, K, max_pivots);
+    (void)hipGetLastError();
+    if (s->A_base[1]) { (void)hipFree(s->A_base[1]); s->A_base[1] = nullptr; }
+    if (s->b_base[1]) { (void)hipFree(s->b_base[1]); s->b_base[1] = nullptr; }
+    s->A2 = nullptr;
+    s->b2 = nullptr;
+  }
   if (int rc = ensure_block_ring(s)) return rc;
   launch_seed_entering(s);
   hipEvent_t* evs = s->ev_batch;
