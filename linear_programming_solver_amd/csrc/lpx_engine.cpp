@@ -532,8 +532,9 @@ static int choose_block(const lpx_state* s) {
   if (K == 0) K = env_int("LPX_BLOCK", 0);
   if (K == 0) {
     const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
+    // measured (scripts/block_policy.py): 32 MiB 57k pivots/s two-launch vs 54k blocked; 64 MiB 33k vs 57k (K = 16);
+    // 512 MiB K = 16 39.7k vs K = 32 37.9k; 1 GiB K = 32 45.8k
     if (sweep_us < 15.0) K = 1;        // cache-resident tableaux: the two-launch loop wins
-    else if (sweep_us < 50.0) K = 8;
     else if (sweep_us < 250.0) K = 16;
     else K = 32;
   }
