@@ -314,6 +314,11 @@ def main():
                          "hbm_moved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else None,
                          "hbm_moved_frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if launches else None,
                          "algorithmic_bytes_per_launch": alg_bytes * pivots_per_launch,
+                         # the update is two unfusable fp64 operations per entry per pivot (product, difference): at
+                         # 32 pivots per sweep that, not HBM, bounds the sweep; peak = 256 CUs x 64
+                         # lanes x 2.4 GHz lane-operations/s (the dense fp64 vector rate counts an FMA as two)
+                         "fp64_valu_Tops": 2.0 * m_local * n * pivots_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None,
+                         "fp64_valu_frac": (2.0 * m_local * n * pivots_per_launch / (avg_ms * 1e-3) / 39.3e12) if launches else None,
                          "whole_pivot_frac": 16.0 * m * n * (K / elapsed) / (HBM_PEAK_GBS * 1e9 * world)},
             "objective_after_timed_region": objective,
             "host_gen_s": t_gen,
