@@ -89,9 +89,9 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   LpxCtl* up;     // kBlockMax parameter blocks (written by finish_pivot)
   int64_t mp;
   // scratch of k_block_chain (single-shard blocks decided in one persistent launch)
-  void* chain_part_a;      // kChainMaxWgs x 32 B
+  void* chain_part_a;      // 2 x kChainMaxWgs x 32 B
   void* chain_part_b;      // kChainMaxWgs x 16 B
-  unsigned* chain_bar;     // 2 counters, 128 B apart; a launch zeroes the next one's
+  unsigned* chain_bar;     // 2 barrier counters + the hand-off word, 128 B apart; a launch zeroes the next one's counter
   double* chain_own_col;   // kBlockMax x mp: copy of `col` that only its writer re-reads (plain, cache-resident)
   double* chain_own_prow;  // kBlockMax x ld: likewise for `prow`
   double* chain_own_dvc;   // kBlockMax x mp: column e_s of the tableau just AFTER pivot s (restart point)

@@ -902,6 +902,8 @@ struct ChainArgs {
   int nb;
   ChainPart* partA;
   RatioRow* partB;
+  unsigned long long* hand;  // {sequence << 32 | entering slot + 2}: workgroup 0's one-way hand-off (see phase B)
+  unsigned hand_base;   // sequence number of this launch's decision 0 (strictly increasing over launches)
   unsigned* bar;        // this launch's barrier counter (zero on entry)
   unsigned* bar_next;   // the next launch's: zeroed here
   int dantzig, fences;
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
       if (w.row != INT_MAX && best.row == w.row) { sh_win[0] = best_a; sh_win[1] = best_b; }
       __syncthreads();
       if (tid == 0) {
-        ChainPart* rec = &P.partA[blockIdx.x];
+        ChainPart* rec = &P.partA[(s & 1) * kChainMaxWgs + blockIdx.x];  // two sets: see the hand-off below
         st_agent(&rec->ratio, w.ratio);
         st_agent(&rec->row, w.row);
         st_agent(&rec->a, (w.row != INT_MAX) ? sh_win[0] : 0.0);
@@ -1032,10 +1034,11 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
     RatioRow mine = rr_none();
     double mine_a = 0.0, mine_b = 0.0;
     if (tid < G) {
-      mine.ratio = ld_agent(&P.partA[tid].ratio);
-      mine.row = ld_agent(&P.partA[tid].row);
-      mine_a = ld_agent(&P.partA[tid].a);
-      mine_b = ld_agent(&P.partA[tid].bi);
+      const ChainPart* rec = &P.partA[(s & 1) * kChainMaxWgs + tid];
+      mine.ratio = ld_agent(&rec->ratio);
+      mine.row = ld_agent(&rec->row);
+      mine_a = ld_agent(&rec->a);
+      mine_b = ld_agent(&rec->bi);
     }
     const RatioRow w = rr_block_min(mine, sh_rr);
     if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
@@ -1092,6 +1095,7 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
       P.own_b[i] = (i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));          // :146 / :164
     }
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
+    const bool window = !P.dantzig && ld >= 256;  // every thread of workgroup 0 then owns one of the slots 0..255
     const double* rowl = A + (int64_t)l * ld;
     for (int j = gid; j < (int)ld; j += T) {
       double x = 0.0;
@@ -1134,6 +1138,20 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
         const RatioRow k2{P.dantzig ? -cn : 0.0, j, 0};
         cand = rr_min(cand, k2);
       }
+      if (window && blockIdx.x == 0 && j == gid) {
+        // Workgroup 0 has just finished slots 0..255.  Under the first-positive rule the next entering slot is the
+        // lowest one with c > eps, so if there is one among them it is the answer, and everything the next phase A
+        // reads about that slot (c[e], the pending pivot rows at e) was written by THIS workgroup, write-through:
+        // drain, meet, and one lane publishes {sequence, slot} in a single 8-byte store.  The others then need no
+        // second grid barrier, only this word.  No candidate here: publish "none", everybody takes the barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const RatioRow w0 = rr_block_min(cand, sh_rr);
+        if (tid == 0) {
+          const unsigned long long rec = ((unsigned long long)(P.hand_base + (unsigned)s) << 32) |
+                                         (unsigned)((w0.row == INT_MAX ? -2 : w0.row) + 2);
+          __hip_atomic_store(P.hand, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
     }
     {
       const RatioRow w2 = rr_block_min(cand, sh_rr);
@@ -1156,17 +1174,37 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
       up.p = p; up.bl = bl; up.e_cur = e; up.l = l; up.e_next = -1; up.parity = 0; up.do_update = 1;
     }
     if (P.dbg && lead) P.dbg[s * 5 + 3] = wall_clock64();
-    target += (unsigned)G;
-    if (!grid_barrier(P.bar, target, &sh_fail, P.fences)) {
-      if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); }
-      return;
+    int e_next = -2;
+    if (window) {  // one lane per workgroup waits for workgroup 0's word (bounded, like the barrier)
+      if (tid == 0) {
+        const unsigned want = P.hand_base + (unsigned)s;
+        unsigned long long rec = 0;
+        unsigned spins = 0;
+        for (;;) {
+          rec = __hip_atomic_load(P.hand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(rec >> 32) == want) break;
+          LPX_BARRIER_SLEEP;
+          if (++spins > (1u << 22)) { sh_fail = 1; break; }
+        }
+        sh_restart = (int)(unsigned)(rec & 0xffffffffu) - 2;
+      }
+      __syncthreads();
+      if (sh_fail) { if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); } return; }
+      e_next = sh_restart;
+      __syncthreads();  // sh_restart is reused by the next phase
+    }
+    if (e_next < 0) {  // no hand-off (Dantzig, narrow tableau) or no candidate in its window: the full exchange
+      target += (unsigned)G;
+      if (!grid_barrier(P.bar, target, &sh_fail, P.fences)) {
+        if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); }
+        return;
+      }
+      RatioRow m2 = rr_none();
+      if (tid < G) { m2.ratio = ld_agent(&P.partB[tid].ratio); m2.row = ld_agent(&P.partB[tid].row); }
+      const RatioRow w3 = rr_block_min(m2, sh_rr);
+      e_next = (w3.row == INT_MAX) ? -1 : w3.row;
     }
     if (P.dbg && lead) P.dbg[s * 5 + 4] = wall_clock64();
-
-    RatioRow m2 = rr_none();
-    if (tid < G) { m2.ratio = ld_agent(&P.partB[tid].ratio); m2.row = ld_agent(&P.partB[tid].row); }
-    const RatioRow w3 = rr_block_min(m2, sh_rr);
-    const int e_next = (w3.row == INT_MAX) ? -1 : w3.row;
     pivots += 1;
     parity ^= 1;
     if (lead) {
@@ -1688,6 +1726,8 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   P.n_old = n_old; P.own_b = R.chain_own_b; P.b_from_tableau = b_from_tableau; P.nb = nb;
   P.partA = reinterpret_cast<ChainPart*>(R.chain_part_a); P.partB = reinterpret_cast<RatioRow*>(R.chain_part_b);
   P.bar = R.chain_bar + 32 * (seq & 1); P.bar_next = R.chain_bar + 32 * ((seq + 1) & 1);
+  P.hand = reinterpret_cast<unsigned long long*>(R.chain_bar + 64);   // its own 128-byte line
+  P.hand_base = (unsigned)(seq + 1) * 64u;  // > any sequence of earlier launches (<= kBlockMax decisions each)
   P.dantzig = dantzig; P.fences = fences; P.host_snap = host_snap; P.dbg = R.chain_dbg;
   hipLaunchKernelGGL(k_block_chain, dim3(G), dim3(256), 0, s, P);
 }
