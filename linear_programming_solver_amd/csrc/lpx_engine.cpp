@@ -658,7 +658,10 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
   // 32 workgroups = one per CU of the reserved XCD; more of them slow the concurrent sweep down more than they
   // speed the decisions up (cfg4: 16 / 32 / 64 workgroups -> 14.1k / 15.0k / 14.0k pivots/s)
   const int64_t work = std::max<int64_t>(s->m, s->B.ld);
-  const int chain_wgs = env_int("LPX_CHAIN_WGS", (int)std::min<int64_t>(32, std::max<int64_t>(1, (work + 511) / 512)));
+  // (+1: with the first-positive rule workgroup 0 serves slots 0..255 only, see k_block_chain)
+  int auto_wgs = (int)std::min<int64_t>(32, std::max<int64_t>(1, (work + 511) / 512));
+  if (s->pricing == 0 && auto_wgs >= 8) auto_wgs += 1;
+  const int chain_wgs = env_int("LPX_CHAIN_WGS", auto_wgs);
   double* Abuf[2] = {s->B.A, s->A2};
   double* bbuf[2] = {s->B.b, s->b2};
   int64_t decided = 0;

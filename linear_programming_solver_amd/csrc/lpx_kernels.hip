@@ -1097,7 +1097,11 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
     const bool window = !P.dantzig && ld >= 256;  // every thread of workgroup 0 then owns one of the slots 0..255
     const double* rowl = A + (int64_t)l * ld;
-    for (int j = gid; j < (int)ld; j += T) {
+    // Column ownership: with the hand-off, workgroup 0 owns slots 0..255 and nothing else (it is on everybody's
+    // critical path), the other workgroups share the rest; fixed for the launch, as the private copies require.
+    const bool solo0 = window && G > 1;
+    const int jstep = solo0 ? T - 256 : T;
+    for (int j = gid; j < (int)ld; j += (solo0 && blockIdx.x == 0) ? (int)ld : jstep) {
       double x = 0.0;
       const double cj = ld_agent(&P.c[j]);  // this thread's own store (or the initial value)
       if (j < n) {
