@@ -1085,15 +1085,6 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
     const int fn_b = rb >= KB ? rb - KB + 1 : 0;
     const double bl = __ddiv_rn(raw_b, p);                                         // :146
     const double inv_p = __ddiv_rn(1.0, p);                                        // :139
-    // the row owners add pivot s to their two running columns: the entering column after the pivot (what a later
-    // decision restarts from) and b
-    for (int i = gid; i < m; i += T) {
-      const double colv = P.own_col[(int64_t)s * mp + i];
-      const double* src_b = use_b ? &b[i] : &P.own_b[i];
-      const double bcur = *src_b;
-      P.own_dvc[(int64_t)s * mp + i] = (i == l) ? inv_p : -__ddiv_rn(colv, p);    // :157 / :139
-      P.own_b[i] = (i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));          // :146 / :164
-    }
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
     const bool window = !P.dantzig && ld >= 256;  // every thread of workgroup 0 then owns one of the slots 0..255
     const double* rowl = A + (int64_t)l * ld;
@@ -1156,6 +1147,15 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
           __hip_atomic_store(P.hand, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+    }
+    // the row owners add pivot s to their two running columns: the entering column after the pivot (what a later
+    // decision restarts from) and b — after the columns, so that workgroup 0 publishes the entering slot first
+    for (int i = gid; i < m; i += T) {
+      const double colv = P.own_col[(int64_t)s * mp + i];
+      const double* src_b = use_b ? &b[i] : &P.own_b[i];
+      const double bcur = *src_b;
+      P.own_dvc[(int64_t)s * mp + i] = (i == l) ? inv_p : -__ddiv_rn(colv, p);    // :157 / :139
+      P.own_b[i] = (i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));          // :146 / :164
     }
     {
       const RatioRow w2 = rr_block_min(cand, sh_rr);
