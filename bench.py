@@ -239,7 +239,10 @@ def main():
         if block < 0:   # one decision incl. the exchange ~60 us; a rank's sweep 16*m_local*n bytes at ~6 TB/s
             sweep_us = 16.0 * (r1 - r0) * n / 6.0e6
             block = 1 if sweep_us <= 50.0 else (16 if sweep_us < 250.0 else 32)
-        eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank, pipeline=args.pipeline if block == 1 else 1)
+        # blocked form: nothing runs beside the sweep, so it keeps all 8 XCDs (the look-ahead pipeline reserves one
+        # for the exchange and the decision kernels)
+        eng = HipShardEngine(A, b, c, r0, m, world, device=local_rank, pipeline=args.pipeline if block == 1 else 1,
+                             reserve_xcds=1 if block == 1 else 0)
         t_up = time.perf_counter() - t_up
         ex = DistExchange()
         status, piv, _ = sharded_simplex_loop([eng], ex, max_pivots=W, poll_every=args.poll_every,
