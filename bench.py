@@ -38,7 +38,87 @@ WORKLOADS = {
     "cfg4_shard2": (16384, 16384),
 }
 HBM_PEAK_GBS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290
+# fp64 vector rate for UNFUSED operations: 256 CUs x 4 SIMDs x 16 fp64 lanes/clk x 2.4 GHz = 39.3 T operations/s.
+# (The 78.6 TFLOP/s vector peak of the data sheet counts an FMA as two; this path must round the product and the
+# difference separately — reference LPState.java:162 — so a multiply and a subtract are one operation each.)
+FP64_VALU_PEAK_TFLOPS = 39.3
 CHUNK = 1024
+
+
+def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traffic=None):
+    """The bounded roofline figure of one row-update / sweep launch.
+    One launch reads and writes every fp64 entry once (16*m*n bytes — counter-verified, profiles/) and performs
+    2*m*n unfusable fp64 operations per pivot it applies.  Its time is bounded below by
+        t_hbm = 16*m*n / 8 TB/s        and        t_valu = 2*m*n*pivots_per_launch / 39.3 Tflop/s
+    frac = max(t_hbm, t_valu) / measured mean launch time (<= 1 by construction), `bound` names the larger term,
+    and achieved/peak are quoted in that bound's unit.  `pivot_equiv_frac` keeps SURVEY 8(d)'s per-PIVOT figure
+    (16*m*n bytes per pivot / 8 TB/s), which exceeds 1 when one sweep applies several pivots."""
+    if not launches or not (avg_ms > 0):
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
+                "kernel": kernel, "launches_sampled": launches}
+    t = avg_ms * 1e-3
+    bytes_moved = 16.0 * m_local * n
+    flops = 2.0 * m_local * n * pivots_per_launch
+    t_hbm = bytes_moved / (HBM_PEAK_GBS * 1e9)
+    t_valu = flops / (FP64_VALU_PEAK_TFLOPS * 1e12)
+    hbm_bound = t_hbm >= t_valu
+    out = {"bound": "hbm" if hbm_bound else "fp64_valu",
+           "achieved": bytes_moved / t / 1e9 if hbm_bound else flops / t / 1e12,
+           "peak": HBM_PEAK_GBS if hbm_bound else FP64_VALU_PEAK_TFLOPS,
+           "unit": "GB/s" if hbm_bound else "TFLOP/s",
+           "frac": max(t_hbm, t_valu) / t,
+           "traffic": traffic,
+           "kernel": kernel, "avg_kernel_ms": avg_ms, "launches_sampled": launches,
+           "pivots_per_launch": pivots_per_launch,
+           "lower_bound_ms": {"hbm": 1e3 * t_hbm, "fp64_valu": 1e3 * t_valu},
+           "hbm_GBps": bytes_moved / t / 1e9, "hbm_frac": t_hbm / t,
+           "fp64_valu_TFLOPs": flops / t / 1e12, "fp64_valu_frac": t_valu / t,
+           "algorithmic_bytes_per_launch": bytes_moved,
+           "pivot_equiv_GBps": bytes_moved * pivots_per_launch / t / 1e9,
+           "pivot_equiv_frac": bytes_moved * pivots_per_launch / t / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
+def load_traffic(workload, world, block):
+    """PMC-measured HBM bytes per launch (profiles/traffic_*.json, scripts/pmc_traffic.py) — only when that file was
+    measured for this workload, GPU count and pivots per sweep; otherwise None."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (workload, world))
+    try:
+        t = json.load(open(tpath))
+        if int(t.get("pivots_per_sweep", -1)) == int(block):
+            return t.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def parity_after(st, A, b, c, pivots, m, n, threads, max_pivots):
+    """Replays `pivots` pivots of the same LP on the fp64 oracle (the checker, not the thing measured) and compares
+    what the timed handle holds now: v, perm, b, c bit for bit and the position-keyed checksum of the tableau."""
+    if pivots > max_pivots:
+        return {"checked": False, "reason": "%d pivots to replay > --parity-max-pivots %d" % (pivots, max_pivots)}
+    from linear_programming_solver_amd.lp_state import checksum_host
+    from oracle import pyoracle as orc
+    orc.build()
+    t0 = time.perf_counter()
+    ref = orc.State(A, b, c, kind=orc.FP64, with_perm=True)
+    r = ref.simplex_loop(max_pivots=pivots, threads=threads)
+    wA, wb, wc, wv, wperm = ref.read()
+    ref.close()
+    _, gb, gc, gv, gperm = st.read(want_A=False)
+    mask = (1 << 64) - 1
+    sa = 0
+    for r0 in range(0, m, 2048):
+        sa = (sa + checksum_host(wA[r0:r0 + 2048], wb[:0], wc[:0], row0=r0)[0]) & mask
+    del wA
+    same = {"v": bool(np.float64(gv).view(np.uint64) == np.float64(wv).view(np.uint64)),
+            "perm": bool(np.array_equal(gperm, wperm)),
+            "b": bool(np.array_equal(gb.view(np.uint64), wb.view(np.uint64))),
+            "c": bool(np.array_equal(gc.view(np.uint64), wc.view(np.uint64))),
+            "A_checksum": bool(st.checksum()[0] == sa)}
+    return {"checked": True, "ok": all(same.values()) and r["pivots"] == pivots, "pivots_replayed": int(r["pivots"]),
+            "bit_identical": same, "oracle": "fp64 restatement, %d threads" % threads,
+            "seconds": time.perf_counter() - t0}
 
 
 def gen_rows(m, n, seed, r0, r1):
@@ -80,8 +160,13 @@ def java_baseline(m_full, n, budget_s):
     import subprocess
     import tempfile
     javac, java = shutil.which("javac"), shutil.which("java")
+    home = os.environ.get("JAVA_HOME")
+    if (not javac or not java) and home:     # a JDK that is installed but not on PATH
+        cand = [os.path.join(home, "bin", x) for x in ("javac", "java")]
+        if all(os.access(x, os.X_OK) for x in cand):
+            javac, java = cand
     if not javac or not java:
-        return {"available": False, "reason": "no JDK on this box (javac/java not on PATH)"}
+        return {"available": False, "reason": "no JDK on this box (javac/java neither on PATH nor under JAVA_HOME)"}
     try:
         out = tempfile.mkdtemp(prefix="lpx_java_")
         subprocess.check_call([javac, "-d", out, os.path.join(ROOT, "bench_java", "PivotBench.java")], timeout=120)
@@ -147,10 +232,15 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("LPX_BENCH_WORKLOAD", "cfg4"), choices=sorted(WORKLOADS))
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--also-cfg3", action="store_true",
-                    help="N=1, cfg4 only: additionally measure cfg3 (BASELINE.md's single-GPU roofline config) in the "
-                         "same process and report it as an extra `cfg3` object (off by default so that a profile of "
-                         "the default command contains ONE workload)")
+    ap.add_argument("--no-cfg3", action="store_true",
+                    help="N=1, cfg4: skip the extra `cfg3` object (BASELINE.md quotes its single-GPU roofline target on "
+                         "cfg3, so it is measured in the same run by default; a profile of ONE workload wants it off)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the oracle replay that checks what the timed region computed")
+    ap.add_argument("--parity-max-pivots", type=int, default=1200,
+                    help="largest warm-up + steps the oracle replay is run for (cfg4: ~30 ms per pivot on 16 threads)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="lpx_state_set_option on the timed handle (names: linear_programming_solver_amd._lib.OPTIONS)")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     ap.add_argument("--poll-every", type=int, default=64,
                     help="sharded runs: pivots issued between two host polls of the replicated status word")
@@ -216,15 +306,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t_up = time.perf_counter()
-    if not sharded:
-        st = LPState(A, b, c, device=local_rank)
+    options = {}
+    for kv in args.option:
+        k, v = kv.split("=", 1)
+        options[k] = int(v)
+
+    def run_single(Aw, bw, cw, mw, nw):
+        """warm-up + timed region of the single-GPU device loop on one workload; returns the measurements"""
+        t_up = time.perf_counter()
+        st = LPState(Aw, bw, cw, device=local_rank, options=options)
         t_up = time.perf_counter() - t_up
         status, piv, _ = st.simplex_loop(max_pivots=W)
         assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
         block = st.block()
-        every = args.event_every if block == 1 else (1 if args.event_every > 0 else 0)  # few, long sweeps: time all
-        st.profile_enable(every)
+        # one-pass form: sample every N-th row update (an event pair costs ~3 us); blocked form: few, long sweeps: all
+        st.profile_enable(args.event_every if block == 1 else (1 if args.event_every > 0 else 0))
         barrier()
         t0 = time.perf_counter()
         status, piv, _ = st.simplex_loop(max_pivots=K)
@@ -232,9 +328,28 @@ def main():
         elapsed = time.perf_counter() - t0
         launches, kernel_ms = st.profile_read()
         st.profile_enable(False)
+        assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
+        if block > 1:
+            # blocked pivoting: blocks of `block` decisions while the budget lasts, the tail (incl. the decision that
+            # only reports the end of the budget) in one last block; a block made of that decision alone has no sweep
+            expect = 0 if args.event_every <= 0 else (K + block) // block if (K % block) else K // block
+            pivots_per_launch = K / float(launches) if launches else float("nan")
+        else:
+            expect = 0 if args.event_every <= 0 else (K + args.event_every - 1) // args.event_every
+            pivots_per_launch = 1.0
+        assert launches == expect, "sampled %d row-update launches, expected %d" % (launches, expect)
+        avg_ms = kernel_ms / launches if launches else float("nan")
+        return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
+                "pivots_per_launch": pivots_per_launch, "upload_s": t_up, "info": st.info()}
+
+    if not sharded:
+        r1_ = run_single(A, b, c, m, n)
+        eng = st = r1_["st"]
+        elapsed, block, launches, avg_ms = r1_["elapsed"], r1_["block"], r1_["launches"], r1_["avg_ms"]
+        pivots_per_launch, t_up, info = r1_["pivots_per_launch"], r1_["upload_s"], r1_["info"]
         objective = st.v
-        eng = st
     else:
+        t_up = time.perf_counter()
         block = args.block
         if block < 0:   # one decision incl. the exchange ~60 us; a rank's sweep 16*m_local*n bytes at ~6 TB/s
             sweep_us = 16.0 * (r1 - r0) * n / 6.0e6
@@ -261,43 +376,20 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
-    if block > 1:
-        # blocked pivoting, sharded driver: ceil((K+1)/block) sweeps (the last decision of a budgeted run only reports
-        # the end).  Single-GPU engine: blocks of `block` decisions while the budget lasts, then powers of two
-        # (lpx_engine.cpp block_len); its overlapped loop issues no sweep for the reporting-only last decision.
-        expect = 0 if args.event_every <= 0 else (K + 1 + block - 1) // block
-        if not sharded and args.event_every > 0:
-            decided, sweeps = 0, 0
-            while decided < K + 1:
-                room = K + 1 - decided
-                nb = block if room >= block else 1 << (room.bit_length() - 1)
-                sweeps += 1
-                decided += nb
-            expect = launches if launches in (sweeps, sweeps - 1) else sweeps
-        sampled_pivots = K                      # every sweep is timed: together they applied all K pivots
-    else:
-        block = 1
-        expect = 0 if args.event_every <= 0 else (K + args.event_every - 1) // args.event_every
-        sampled_pivots = launches
-    assert launches == expect, "sampled %d row-update launches, expected %d" % (launches, expect)
+        assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
+        info = None
+        if block > 1:   # ceil((K+1)/block) sweeps (the last decision of a budgeted run only reports the end)
+            expect = 0 if args.event_every <= 0 else (K + 1 + block - 1) // block
+            pivots_per_launch = K / float(launches) if launches else float("nan")
+        else:
+            block = 1
+            expect = 0 if args.event_every <= 0 else (K + args.event_every - 1) // args.event_every
+            pivots_per_launch = 1.0
+        assert launches == expect, "sampled %d row-update launches, expected %d" % (launches, expect)
+        avg_ms = kernel_ms / launches if launches else float("nan")
 
     if rank == 0:
         m_local = r1 - r0
-        alg_bytes = 16.0 * m_local * n                       # SURVEY §8d per PIVOT: every fp64 entry read + written once
-        avg_ms = kernel_ms / launches if launches else float("nan")
-        pivots_per_launch = sampled_pivots / launches if launches else float("nan")
-        # contract: algorithmic bytes per launch (per-pivot figure x pivots one launch applies) / mean duration.
-        # With blocked pivoting one sweep applies several pivots while moving each entry once, so this exceeds
-        # what the sweep really moves (hbm_bytes_moved_per_launch) — and can exceed the HBM peak.
-        achieved = alg_bytes * pivots_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (args.workload, world))
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         line = {
             "metric": "simplex_pivots_per_sec", "value": K / elapsed, "unit": "pivots/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
@@ -309,47 +401,36 @@ def main():
                        "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot, %s" % (
                            world, ("blocked x%d" % block) if block > 1 else
                            ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline))},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_update" if block == 1 else "k_update_multi", "avg_kernel_ms": avg_ms,
-                         "launches_sampled": launches, "pivots_per_launch": pivots_per_launch,
-                         "hbm_bytes_moved_per_launch": alg_bytes,
-                         "hbm_moved_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else None,
-                         "hbm_moved_frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if launches else None,
-                         "algorithmic_bytes_per_launch": alg_bytes * pivots_per_launch,
-                         # the update is two unfusable fp64 operations per entry per pivot (product, difference): at
-                         # 32 pivots per sweep that, not HBM, bounds the sweep; peak = 256 CUs x 64
-                         # lanes x 2.4 GHz lane-operations/s (the dense fp64 vector rate counts an FMA as two)
-                         "fp64_valu_Tops": 2.0 * m_local * n * pivots_per_launch / (avg_ms * 1e-3) / 1e12 if launches else None,
-                         "fp64_valu_frac": (2.0 * m_local * n * pivots_per_launch / (avg_ms * 1e-3) / 39.3e12) if launches else None,
-                         "whole_pivot_frac": 16.0 * m * n * (K / elapsed) / (HBM_PEAK_GBS * 1e9 * world)},
+            "roofline": roofline_block(m_local, n, pivots_per_launch, avg_ms,
+                                       "k_update" if block == 1 else "k_update_multi", launches,
+                                       load_traffic(args.workload, world, block)),
             "objective_after_timed_region": objective,
             "host_gen_s": t_gen,
             "host_upload_s": t_up,   # hipMalloc + PCIe upload of this rank's tableau; outside the timed region
         }
-        if world == 1 and not sharded and args.workload == "cfg4" and args.also_cfg3:
+        if info is not None:   # what the engine actually did: grid of the decision kernel, its residency bound, CU masks
+            line["engine"] = info
+        if world == 1 and not sharded and not args.no_parity:
+            # the checker: the same LP replayed on the fp64 oracle for warm-up + steps pivots (outside the timed region)
+            line["parity_after_timed_region"] = parity_after(st, A, b, c, W + K, m, n, host_cores(), args.parity_max_pivots)
+        if world == 1 and not sharded and args.workload == "cfg4" and not args.no_cfg3:
             # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
             # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)
             st.close()
             m3, n3 = WORKLOADS["cfg3"]
             A3, b3, c3 = gen_rows(m3, n3, args.seed, 0, m3)
-            st3 = LPState(A3, b3, c3, device=local_rank)
-            st3.simplex_loop(max_pivots=W)
-            st3.profile_enable(args.event_every)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            s3, p3, _ = st3.simplex_loop(max_pivots=K)
-            torch.cuda.synchronize()
-            e3 = time.perf_counter() - t0
-            l3, ms3 = st3.profile_read()
-            st3.close()
-            if p3 == K and l3 > 0:
-                ach3 = 16.0 * m3 * n3 / (ms3 / l3 * 1e-3) / 1e9
-                line["cfg3"] = {"workload": "cfg3: m=8192 n=16384, %d pivots after %d warm-up" % (K, W),
-                                "value": K / e3, "unit": "pivots/s", "ms_per_step": 1e3 * e3 / K,
-                                "roofline": {"bound": "hbm", "achieved": ach3, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": ach3 / HBM_PEAK_GBS, "avg_kernel_ms": ms3 / l3,
-                                             "whole_pivot_frac": 16.0 * m3 * n3 * (K / e3) / (HBM_PEAK_GBS * 1e9)}}
+            r3 = run_single(A3, b3, c3, m3, n3)
+            line["cfg3"] = {"workload": "cfg3: m=8192 n=16384, %d pivots after %d warm-up" % (K, W),
+                            "value": K / r3["elapsed"], "unit": "pivots/s", "ms_per_step": 1e3 * r3["elapsed"] / K,
+                            "pivots_per_sweep": r3["block"],
+                            "roofline": roofline_block(m3, n3, r3["pivots_per_launch"], r3["avg_ms"],
+                                                       "k_update" if r3["block"] == 1 else "k_update_multi",
+                                                       r3["launches"], load_traffic("cfg3", 1, r3["block"]))}
+            if not args.no_parity:
+                line["cfg3"]["parity_after_timed_region"] = parity_after(r3["st"], A3, b3, c3, W + K, m3, n3,
+                                                                         host_cores(), args.parity_max_pivots)
+            r3["st"].close()
+            del A3, b3, c3
         if world == 1 and not args.no_cpu_baseline:
             rows_s = min(m, 8192)
             line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LPX_ABI_VERSION 1
+#define LPX_ABI_VERSION 2
 
 /* Status codes.  One per exception message of the reference; the host shim maps them back
  * to the exact exception class + message because the reference's tests assert on the text. */
@@ -111,6 +111,53 @@ int lpx_get_leaving(lpx_state* s, int32_t entering, int32_t* leaving, double* ra
  * slot/basis swap in perm.  `leaving` is a row index in [0,m).  A zero pivot element returns
  * LPX_DIVIDE_BY_ZERO and leaves the state untouched.  Single-GPU handles only. */
 int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving);
+
+/* Tuning and diagnostic options of ONE handle (they replace the LPX_* environment knobs of the first version:
+ * a JVM host sets them through the handle, not through its process environment).  Every option has a measured
+ * default; the LPX_<NAME> environment variables are read ONCE per process, before the first handle is created, and
+ * only supply the initial values (debugging aid for the scripts/ helpers).  Setting an option between two loops
+ * is allowed; inside a loop nothing reads them.  Unknown key / value out of range -> LPX_BAD_ARGUMENT. */
+typedef enum lpx_option {
+  LPX_OPT_BLOCK = 0,          /* pivots per sweep: 0 = by size, 1 = off, 2..32 (same as lpx_state_set_block)        */
+  LPX_OPT_CHAIN = 1,          /* 1 = all decisions of a block in one persistent launch (default); 0 = three launches */
+  LPX_OPT_OVERLAP = 2,        /* 1 = decisions of block k+1 beside the sweep of block k (default); 0 = serial        */
+  LPX_OPT_OVERLAP_SERIAL = 3, /* 1 = the overlapped loop's kernels and buffers without concurrency (diagnostics)     */
+  LPX_OPT_OVERLAP_MASK = 4,   /* 1 = CU-masked streams: one XCD for the decisions, seven for the sweep (default)     */
+  LPX_OPT_CHAIN_WGS = 5,      /* workgroups of the decision kernel; 0 = by size; always clamped to what is resident  */
+  LPX_OPT_CHAIN_FENCES = 6,   /* grid barrier of the decision kernel: bit 0 release fence, bit 1 acquire fence       */
+  LPX_OPT_SWEEP_ROWS = 7,     /* rows per workgroup of the blocked sweep; 0 = by size                                */
+  LPX_OPT_NT = 8,             /* non-temporal tableau loads/stores: -1 = by size, 0, 1                               */
+  LPX_OPT_BATCH = 9,          /* one-pass loop: pivots issued between two host polls; 0 = by size                    */
+  LPX_OPT_CHAIN_TRACE = 10,   /* 1 = keep phase timestamps of the last decision launch (lpx_state_read_chain_trace)  */
+  LPX_OPT_UPDATE_U = 11,      /* one-pass update: 16-byte accesses per thread per row (1, 2, 4)                      */
+  LPX_OPT_UPDATE_ROWS = 12,   /* one-pass update: rows per workgroup (even, 2..256)                                  */
+  LPX_OPT_A2_OFFSET = 13,     /* skew between the two tableau buffers in doubles (before the second one exists)      */
+  LPX_OPT_COUNT = 14
+} lpx_option;
+int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value);
+int lpx_state_get_option(const lpx_state* s, int32_t key, int64_t* value);
+
+/* What the handle actually did (the by-size choices, and whether the placement assumptions of the blocked loop
+ * held on this runtime); filled from the last lpx_simplex_loop. */
+typedef struct lpx_state_info {
+  int32_t block;                /* pivots per sweep in effect                                                      */
+  int32_t chain_wgs;            /* workgroups of the last decision launch (after the residency clamp)              */
+  int32_t chain_wgs_requested;  /* before the clamp                                                                */
+  int32_t chain_resident_max;   /* hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs the launch could use         */
+  int32_t chain_blocks_per_cu;  /* the occupancy API's answer for the decision kernel                              */
+  int32_t chain_stream_masked;  /* 1: the CU-masked stream pair was created; 0: plain streams (priority only)      */
+  int32_t chain_xcd_mask;       /* bit x set: a workgroup of the last decision launch ran on XCD x (HW_REG_XCC_ID) */
+  int32_t sweep_xcd_mask;       /* likewise for the sampled workgroups of the last blocked sweep                   */
+  int32_t overlapped;           /* 1: the last blocked loop ran decisions beside sweeps (two tableau buffers)      */
+  int32_t nontemporal;          /* tableau accesses are non-temporal                                               */
+  int32_t sweep_rows;           /* rows per workgroup of the last blocked sweep                                    */
+  int32_t reserved;
+} lpx_state_info;
+int lpx_state_get_info(lpx_state* s, lpx_state_info* out);
+/* Phase timestamps of the last decision launch (LPX_OPT_CHAIN_TRACE = 1): 5 ticks (100 MHz) per decision —
+ * start, phase A done, barrier passed, phase B done, next entering slot known.  ticks has room for 5 * cap
+ * values; *ndecisions = decisions of the last launch that are present. */
+int lpx_state_read_chain_trace(lpx_state* s, int64_t* ticks, int32_t cap, int32_t* ndecisions);
 
 /* Pivots per pass over the tableau in lpx_simplex_loop / lpx_solve ("blocked pivoting"): K pivot decisions are
  * taken from the not-yet-updated tableau (each needs one column and one row, recovered by the pending pivots'
@@ -231,11 +278,14 @@ typedef struct lpx_solve_options {
   const int32_t* restore_order; /* iteration order of initial.coefficients.keySet() in restoreInitialLP   */
                                 /* (LPSolver.java:213-217) as original-variable indices; NULL = the order */
                                 /* java.util.HashMap gives the default names "x1".."xn" (:388-400)        */
-  int32_t* perm_out;            /* optional int32[n+m]: final slot -> variable id                         */
+  int32_t* perm_out;            /* optional int32[n+m]: final slot -> variable id.  Written only when the result */
+                                /* is an m x n state (phase 2 reached): a solve that ends inside phase 1        */
+                                /* (INFEASIBLE, AUX_UNBOUNDED, ...) leaves it untouched                          */
   double* x_out;                /* optional double[n]: primal solution (basic slot -> b[i], else 0)       */
   lpx_state** keep_state;       /* optional: receive the final LPState handle instead of destroying it    */
   int32_t pricing;              /* 0 = the reference's entering rule (default); 1 = Dantzig, see            */
-  int32_t reserved;             /* lpx_state_set_pricing                                                   */
+                                /* lpx_state_set_pricing                                                   */
+  int32_t restore_order_len;    /* entries of restore_order; <= 0: n (every original variable has a name)  */
 } lpx_solve_options;
 
 /* BigDecimal LPSolver.solve(LPStandardForm stForm)                      LPSolver.java:78
@@ -249,11 +299,12 @@ int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, const double* 
 
 /* LPState restoreInitialLP(auxLP, initial, indexOfX0)                   LPSolver.java:200-246
  * In place on the auxiliary-LP handle (m x (n+1), as left by phase 1): drops x0's column, rebuilds c and v by
- * substitution in keySet() order (`order`, n original-variable indices; NULL = default-name order), renumbers
+ * substitution in keySet() order (`order`, order_len <= n original-variable indices; NULL = default-name order of all n), renumbers
  * the slots above x0; the handle then is the m x n LPState the reference constructs at :245.  Bug-for-bug with
  * the reference (a nonbasic original variable is credited at its aux-LP slot; slot n returns
  * LPX_RESTORE_INDEX_FAULT).  c0 = initial.c (already negated for `min`). */
-int lpx_restore_initial_lp(lpx_state* aux, const double* c0, int32_t n, int32_t x0_slot, const int32_t* order);
+int lpx_restore_initial_lp(lpx_state* aux, const double* c0, int32_t n, int32_t x0_slot, const int32_t* order,
+                           int32_t order_len);
 
 /* Iteration order of a java.util.HashMap<String,Integer> filled by put("x1"), put("x2"), ... put("xn")
  * into a default-constructed map (LPSolver.addDefaultVariables, LPSolver.java:388-400): writes the

@@ -8,6 +8,7 @@ if [ -z "$JAVA_HOME" ]; then
   [ -n "$JAVAC" ] || { echo "no JDK found (set JAVA_HOME)"; exit 2; }
   JAVA_HOME=$(dirname "$(dirname "$(readlink -f "$JAVAC")")")
 fi
+[ -f "$JAVA_HOME/include/jni.h" ] || { echo "no jni.h under $JAVA_HOME/include (a JRE without headers?)"; exit 2; }
 LIBDIR="$HERE/../linear_programming_solver_amd"
 [ -f "$LIBDIR/liblpx.so" ] || make -C "$LIBDIR/csrc"
 cc -O2 -fPIC -shared -I"$JAVA_HOME/include" -I"$JAVA_HOME/include/linux" "$HERE/lpx_jni.c" \

@@ -12,6 +12,11 @@ OPTIMAL, UNBOUNDED, INFEASIBLE, AUX_UNBOUNDED, NO_DEGENERATE_PIVOT, BAD_ARGUMENT
 CAND_HEADER = 8
 PRICING = {"reference": 0, "first-positive": 0, "dantzig": 1, 0: 0, 1: 1}
 
+# lpx_option (include/lpx.h)
+OPTIONS = {"block": 0, "chain": 1, "overlap": 2, "overlap_serial": 3, "overlap_mask": 4, "chain_wgs": 5,
+           "chain_fences": 6, "sweep_rows": 7, "nt": 8, "batch": 9, "chain_trace": 10, "update_u": 11,
+           "update_rows": 12, "a2_offset": 13}
+
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
 i64p = C.POINTER(C.c_int64)
@@ -33,6 +38,13 @@ class SolveResult(C.Structure):
     ]
 
 
+class StateInfo(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in (
+        "block", "chain_wgs", "chain_wgs_requested", "chain_resident_max", "chain_blocks_per_cu",
+        "chain_stream_masked", "chain_xcd_mask", "sweep_xcd_mask", "overlapped", "nontemporal", "sweep_rows",
+        "reserved")]
+
+
 class SolveOptions(C.Structure):
     _fields_ = [
         ("device", C.c_int32),
@@ -43,7 +55,7 @@ class SolveOptions(C.Structure):
         ("x_out", dp),
         ("keep_state", C.POINTER(C.c_void_p)),
         ("pricing", C.c_int32),
-        ("reserved", C.c_int32),
+        ("restore_order_len", C.c_int32),
     ]
 
 
@@ -64,6 +76,10 @@ SYMBOLS = [
     ("lpx_state_set_pricing", C.c_int, [C.c_void_p, C.c_int32]),
     ("lpx_state_set_block", C.c_int, [C.c_void_p, C.c_int32]),
     ("lpx_state_get_block", C.c_int, [C.c_void_p]),
+    ("lpx_state_set_option", C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    ("lpx_state_get_option", C.c_int, [C.c_void_p, C.c_int32, i64p]),
+    ("lpx_state_get_info", C.c_int, [C.c_void_p, C.POINTER(StateInfo)]),
+    ("lpx_state_read_chain_trace", C.c_int, [C.c_void_p, i64p, C.c_int32, ip]),
     ("lpx_get_entering", C.c_int, [C.c_void_p, ip]),
     ("lpx_get_leaving", C.c_int, [C.c_void_p, C.c_int32, ip, dp]),
     ("lpx_pivot", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -88,7 +104,7 @@ SYMBOLS = [
     ("lpx_shard_poll", C.c_int, [C.c_void_p, i64p, ip]),
     ("lpx_solve", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(SolveOptions),
                             C.POINTER(SolveResult)]),
-    ("lpx_restore_initial_lp", C.c_int, [C.c_void_p, dp, C.c_int32, C.c_int32, ip]),
+    ("lpx_restore_initial_lp", C.c_int, [C.c_void_p, dp, C.c_int32, C.c_int32, ip, C.c_int32]),
     ("lpx_java_default_name_order", C.c_int, [C.c_int32, ip]),
     ("lpx_transpose", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, C.c_int64, C.c_int]),
 ]

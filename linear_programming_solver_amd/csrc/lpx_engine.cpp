@@ -72,13 +72,15 @@ struct lpx_state {
   Geometry g{};
   bool nontemporal = false;
   int pricing = 0;                  // 0 = reference rule (first positive), 1 = Dantzig (opt-in extension)
-  // blocked pivoting (K decisions from the stale tableau, then one sweep): 0 = choose by size, 1 = off
-  int block = 0;
-  int sweep_rows = 0;  // 0: launch_block_sweep chooses
+  int64_t opt[LPX_OPT_COUNT] = {};  // lpx_option values (include/lpx.h); initial values: env_defaults()
+  lpx_state_info info{};            // what the last loop actually did (lpx_state_get_info)
+  int chain_nb_last = 0;            // decisions of the last k_block_chain launch (chain trace)
   lpxk::BlockRing R{};
   int chain_seq = 0;                // k_block_chain launches so far (its two barrier counters alternate)
   // overlapped blocked loop: decisions of block k+1 (one reserved XCD) beside the sweep of block k (the other 7)
   hipStream_t ov_chain = nullptr, ov_sweep = nullptr;
+  bool ov_masked = false;           // the pair was created with CU masks (else: plain streams, chain at high priority)
+  int ov_chain_cus = 0;             // CUs the chain stream may use
   hipEvent_t ev_ov_chain[2] = {nullptr, nullptr}, ev_ov_sweep[2] = {nullptr, nullptr}, ev_ov_join[3] = {nullptr, nullptr, nullptr};
   double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
@@ -110,29 +112,71 @@ struct lpx_state {
 
 static int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
-static int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
+// Option defaults.  The LPX_<NAME> environment variables are read exactly once per process (debugging aid for the
+// scripts/ helpers, which run one configuration per process); everything after that goes through the handle
+// (lpx_state_set_option): no getenv in the pivot path.
+struct OptionSpec { const char* env; int64_t dflt, lo, hi; };
+static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
+    {"LPX_BLOCK", 0, 0, lpxk::kBlockMax},   // LPX_OPT_BLOCK
+    {"LPX_CHAIN", 1, 0, 1},                 // LPX_OPT_CHAIN
+    {"LPX_OVERLAP", 1, 0, 1},               // LPX_OPT_OVERLAP
+    {"LPX_OVERLAP_SERIAL", 0, 0, 1},        // LPX_OPT_OVERLAP_SERIAL
+    {"LPX_OVERLAP_MASK", 1, 0, 1},          // LPX_OPT_OVERLAP_MASK
+    {"LPX_CHAIN_WGS", 0, 0, lpxk::kChainMaxWgs},  // LPX_OPT_CHAIN_WGS
+    {"LPX_CHAIN_FENCES", 2, 0, 3},          // LPX_OPT_CHAIN_FENCES
+    {"LPX_SWEEP_ROWS", 0, 0, 128},          // LPX_OPT_SWEEP_ROWS
+    {"LPX_NT", -1, -1, 1},                  // LPX_OPT_NT
+    {"LPX_BATCH", 0, 0, 4096},              // LPX_OPT_BATCH
+    {"LPX_CHAIN_TRACE", 0, 0, 1},           // LPX_OPT_CHAIN_TRACE
+    {"LPX_U", 1, 1, 4},                     // LPX_OPT_UPDATE_U
+    {"LPX_ROWS_PER_TILE", 2, 2, 256},       // LPX_OPT_UPDATE_ROWS
+    {"LPX_A2_OFFSET", 512, 0, 1 << 20},     // LPX_OPT_A2_OFFSET
+};
+
+static const int64_t* env_defaults() {
+  static int64_t d[LPX_OPT_COUNT];
+  static const bool once = [] {
+    for (int k = 0; k < LPX_OPT_COUNT; k++) {
+      const OptionSpec& sp = kOptionSpec[k];
+      int64_t v = sp.dflt;
+      const char* e = getenv(sp.env);
+      if (e && *e) v = std::max(sp.lo, std::min(sp.hi, (int64_t)atoll(e)));
+      d[k] = v;
+    }
+    return true;
+  }();
+  (void)once;
+  return d;
 }
 
 // Tiling of k_update.
-static Geometry choose_geometry(int m, int64_t ld) {
+static Geometry choose_geometry(int m, int64_t ld, const int64_t* opt) {
   // Measured on MI355X (profiles/r01_sweep_*.log): one row PAIR x 512 columns per workgroup is fastest at
   // every size (cfg3 6.3 TB/s vs 5.3 TB/s for 32-row x 2048-column tiles): consecutive workgroups then sweep
   // the tableau in address order and the tail of the grid is negligible.
   Geometry g{};
-  int U = env_int("LPX_U", 1);
+  int U = (int)opt[LPX_OPT_UPDATE_U];
   if (U != 1 && U != 2 && U != 4) U = 1;
   g.U = U;
   const int W = 512 * U;
   g.nstrips = (int)((ld + W - 1) / W);
-  int R = env_int("LPX_ROWS_PER_TILE", 2);
+  int R = (int)opt[LPX_OPT_UPDATE_ROWS];
   if (R < 2) R = 2;
   if (R > 256) R = 256;  // the seed/peek kernels emit one partial per 256 rows into the same buffer
   if (R & 1) R += 1;  // rows are processed in pairs
   g.rows_per_tile = R;
   g.ntiles = m > 0 ? (m + R - 1) / R : 0;
   return g;
+}
+
+// The by-size choices that depend on options: k_update's tiling and the cache policy of the tableau accesses.
+static void apply_layout_options(lpx_state* s) {
+  s->g = choose_geometry(s->m, s->B.ld, s->opt);
+  // non-temporal streaming only pays once the tableau no longer fits the 256 MiB Infinity Cache
+  const int64_t bytes = (int64_t)s->m * s->B.ld * 8;
+  const int64_t nt = s->opt[LPX_OPT_NT];
+  s->nontemporal = nt < 0 ? bytes > (192ll << 20) : nt != 0;
+  s->info.nontemporal = s->nontemporal ? 1 : 0;
 }
 
 static int sync_ctl_to_host(lpx_state* s) {
@@ -178,6 +222,7 @@ static void free_state(lpx_state* s) {
   (void)hipFree(s->R.chain_own_dvc);
   (void)hipFree(s->R.chain_own_b);
   (void)hipFree(s->R.chain_dbg);
+  (void)hipFree(s->R.census);
   (void)hipFree(s->d_cand);
   if (s->ev_upd) (void)hipEventDestroy(s->ev_upd);
 
@@ -210,10 +255,8 @@ static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, 
   const int64_t ld = std::max<int64_t>(16, round_up(n_cap, 16));
   const int64_t mp = std::max<int64_t>(2, round_up(m_local, 2)) + 2;
   s->B.ld = ld;
-  s->g = choose_geometry(m_local, ld);
-  // non-temporal streaming only pays once the tableau no longer fits the 256 MiB Infinity Cache
-  const int64_t bytes = (int64_t)m_local * ld * 8;
-  s->nontemporal = env_int("LPX_NT", bytes > (192ll << 20) ? 1 : 0) != 0;
+  memcpy(s->opt, env_defaults(), sizeof s->opt);
+  apply_layout_options(s);
 #define ALLOC(ptr, count, type)                                                            \
   do {                                                                                     \
     hipError_t _e = hipMalloc((void**)&(ptr), std::max<size_t>(1, (size_t)(count)) * sizeof(type)); \
@@ -229,7 +272,7 @@ static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, 
   ALLOC(s->B.prow, ld, double);
   ALLOC(s->B.col[0], mp, double);
   ALLOC(s->B.col[1], mp, double);
-  ALLOC(s->B.partial, std::max(1, s->g.ntiles), RatioRow);
+  ALLOC(s->B.partial, std::max(1, (m_local + 1) / 2 + 1), RatioRow);  // room for the finest tiling (2 rows per tile)
   ALLOC(s->B.perm, (int64_t)n_cap + m_global, int32_t);
   ALLOC(s->B.ctl, 1, LpxCtl);
   ALLOC(s->d_sum, 4, unsigned long long);
@@ -494,10 +537,10 @@ static int ensure_block_ring(lpx_state* s) {
   HIP_TRY(hipMalloc((void**)&s->R.chain_own_b, (size_t)mp * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.chain_own_col, 0, K * (size_t)mp * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.chain_own_prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
-  if (getenv("LPX_CHAIN_TRACE")) {
-    HIP_TRY(hipMalloc((void**)&s->R.chain_dbg, 5 * lpxk::kBlockMax * sizeof(long long)));
-    HIP_TRY(hipMemsetAsync(s->R.chain_dbg, 0, 5 * lpxk::kBlockMax * sizeof(long long), s->stream));
-  }
+  HIP_TRY(hipMalloc((void**)&s->R.chain_dbg, 5 * lpxk::kBlockMax * sizeof(long long)));
+  HIP_TRY(hipMemsetAsync(s->R.chain_dbg, 0, 5 * lpxk::kBlockMax * sizeof(long long), s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.census, (lpxk::kChainMaxWgs + 2) * sizeof(unsigned)));
+  HIP_TRY(hipMemsetAsync(s->R.census, 0, (lpxk::kChainMaxWgs + 2) * sizeof(unsigned), s->stream));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));
@@ -512,7 +555,7 @@ static int ensure_spare_tableau(lpx_state* s) {
   const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
   // 4 KiB skew between the two buffers: measured 346 us vs 354 us per cfg3 update with none (the read and the
   // write stream then do not hit the same HBM channel at the same time); profiles/r01_cu_mask.log
-  const int64_t off = env_int("LPX_A2_OFFSET", 512);  // in doubles
+  const int64_t off = s->opt[LPX_OPT_A2_OFFSET];  // in doubles
   HIP_TRY(hipMalloc((void**)&s->A_base[1], (size_t)(mp * s->B.ld + off) * sizeof(double)));
   s->A2 = s->A_base[1] + off;
   HIP_TRY(hipMalloc((void**)&s->b_base[1], (size_t)mp * sizeof(double)));
@@ -528,8 +571,7 @@ static int ensure_spare_tableau(lpx_state* s) {
 // and at ~4.7 TB/s at K = 32 (there the 2K fp64 operations per entry co-limit it); the one-pass form costs one
 // pass at ~6.3 TB/s + ~9 us per pivot.  Per pivot: blocked(K) ~ 18 + 0.4 K/2 + sweep(K)/K.
 static int choose_block(const lpx_state* s) {
-  int K = s->block;
-  if (K == 0) K = env_int("LPX_BLOCK", 0);
+  int K = (int)s->opt[LPX_OPT_BLOCK];
   if (K == 0) {
     const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
     // measured (scripts/block_policy.py): 32 MiB 57k pivots/s two-launch vs 54k blocked; 64 MiB 33k vs 57k (K = 16);
@@ -541,28 +583,32 @@ static int choose_block(const lpx_state* s) {
   return std::max(1, std::min(K, (int)lpxk::kBlockMax));
 }
 
-// Decisions of the next block: K while the budget lasts, then powers of two, so that every sweep applies exactly
-// as many pivots as one of its template instances is built for (a partly filled instance takes the guarded path).
+// Decisions of the next block: K while the budget lasts, then whatever is left INCLUDING the decision that only
+// reports the end of the budget — one block, one sweep for the tail (the sweep kernels take any number of pending
+// pivots up to their template size at full speed, see sweep_apply).
 static int block_len(int K, int64_t max_pivots, int64_t decided) {
   if (max_pivots < 0) return K;
   const int64_t room = max_pivots + 1 - decided;  // +1: the decision that reports PIVOT_LIMIT
-  if (room >= K) return K;
-  if (room <= 0) return 0;
-  int nb = 1;
-  while (2 * nb <= room) nb *= 2;
-  return nb;
+  return (int)std::max<int64_t>(0, std::min<int64_t>(K, room));
 }
 
-// LPX_CHAIN_TRACE=<file>: phase timestamps (100 MHz ticks) of the last k_block_chain launch (diagnostics)
-static void dump_chain_trace(lpx_state* s) {
-  if (!s->R.chain_dbg) return;
-  long long h[5 * lpxk::kBlockMax];
-  if (hipMemcpy(h, s->R.chain_dbg, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
-  if (FILE* f = fopen(getenv("LPX_CHAIN_TRACE"), "w")) {
-    for (int k = 0; k < lpxk::kBlockMax; k++)
-      fprintf(f, "%d %lld %lld %lld %lld %lld\n", k, h[5 * k], h[5 * k + 1], h[5 * k + 2], h[5 * k + 3], h[5 * k + 4]);
-    fclose(f);
-  }
+// Residency of the persistent decision kernel: every workgroup spins at grid barriers, so the grid must not exceed
+// what the CUs it may use can hold at once.  cus = the CUs of the stream's mask (all of them without a mask).
+static int clamp_chain_wgs(lpx_state* s, int want, int cus) {
+  const int per_cu = lpxk::chain_blocks_per_cu();
+  const int cap = std::max(1, per_cu * std::max(1, cus));
+  s->info.chain_blocks_per_cu = per_cu;
+  s->info.chain_resident_max = cap;
+  s->info.chain_wgs_requested = want;
+  const int G = std::max(1, std::min(std::min(want, cap), (int)lpxk::kChainMaxWgs));
+  s->info.chain_wgs = G;
+  return G;
+}
+
+static int device_cus(const lpx_state* s) {
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess) ncu = 0;
+  return ncu;
 }
 
 // B / R: destination buffers and the ring half of the block; A_src / b_src != NULL: out of place
@@ -579,8 +625,9 @@ static int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const 
     }
     HIP_TRY(hipEventRecord(s->ev[s->ev_used], stream));
   }
-  lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, env_int("LPX_SWEEP_ROWS", s->sweep_rows), s->nontemporal,
-                           stream, A_src, b_src, sample ? s->ev[s->ev_used + 1] : nullptr);
+  s->info.sweep_rows = lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, (int)s->opt[LPX_OPT_SWEEP_ROWS],
+                                                s->nontemporal, stream, A_src, b_src,
+                                                sample ? s->ev[s->ev_used + 1] : nullptr);
   if (sample) s->ev_used += 2;
   HIP_TRY(hipGetLastError());
   return 0;
@@ -613,7 +660,7 @@ static int ensure_overlap_streams(lpx_state* s) {
     else m_sweep[cu / 32] |= 1u << (cu % 32);
   }
   bool masked = false;
-  if (env_int("LPX_OVERLAP_MASK", 1) != 0 && ncu >= 64) {
+  if (s->opt[LPX_OPT_OVERLAP_MASK] != 0 && ncu >= 64) {
     masked = hipExtStreamCreateWithCUMask(&s->ov_chain, (uint32_t)m_chain.size(), m_chain.data()) == hipSuccess &&
              hipExtStreamCreateWithCUMask(&s->ov_sweep, (uint32_t)m_sweep.size(), m_sweep.data()) == hipSuccess;
     if (!masked) {  // no CU masking on this runtime: plain streams below (same results, less isolation)
@@ -628,6 +675,8 @@ static int ensure_overlap_streams(lpx_state* s) {
     HIP_TRY(hipStreamCreateWithPriority(&s->ov_chain, hipStreamNonBlocking, hi));
     HIP_TRY(hipStreamCreateWithFlags(&s->ov_sweep, hipStreamNonBlocking));
   }
+  s->ov_masked = masked;
+  s->ov_chain_cus = masked ? ncu / 8 : ncu;
   for (int k = 0; k < 2; k++) {
     HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_chain[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_sweep[k], hipEventDisableTiming));
@@ -661,12 +710,18 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
   // (+1: with the first-positive rule workgroup 0 serves slots 0..255 only, see k_block_chain)
   int auto_wgs = (int)std::min<int64_t>(32, std::max<int64_t>(1, (work + 511) / 512));
   if (s->pricing == 0 && auto_wgs >= 8) auto_wgs += 1;
-  const int chain_wgs = env_int("LPX_CHAIN_WGS", auto_wgs);
+  // never more workgroups than the chain stream's CUs can hold at once: they spin at grid barriers
+  const int chain_wgs = clamp_chain_wgs(s, s->opt[LPX_OPT_CHAIN_WGS] > 0 ? (int)s->opt[LPX_OPT_CHAIN_WGS] : auto_wgs,
+                                        s->ov_chain_cus);
+  const int fences = (int)s->opt[LPX_OPT_CHAIN_FENCES];
+  const bool trace = s->opt[LPX_OPT_CHAIN_TRACE] != 0;
+  s->info.chain_stream_masked = s->ov_masked ? 1 : 0;
+  s->info.overlapped = 1;
   double* Abuf[2] = {s->B.A, s->A2};
   double* bbuf[2] = {s->B.b, s->b2};
   int64_t decided = 0;
   int nb_prev = 0, nblk = 0;
-  const bool serial = env_int("LPX_OVERLAP_SERIAL", 0) != 0;
+  const bool serial = s->opt[LPX_OPT_OVERLAP_SERIAL] != 0;
   auto issue_block = [&](int k) -> int {  // 1: the budget is spent, nothing issued
     const int nb = block_len(K, max_pivots, decided);
     if (nb <= 0) return 1;
@@ -677,14 +732,15 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
       Brd.A = Abuf[h];
       Brd.b = bbuf[h];
       lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, 0, 1, s->chain_seq++, s->pricing == 1, chain_wgs,
-                               d_snap + h, s->ov_chain);
+                               fences, trace, d_snap + h, s->ov_chain);
     } else {
       if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h], 0));  // sweep k-2
       Brd.A = Abuf[k == 0 ? 0 : (k - 1) & 1];
       Brd.b = bbuf[k == 0 ? 0 : (k - 1) & 1];
       lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0, s->chain_seq++,
-                               s->pricing == 1, chain_wgs, d_snap + h, s->ov_chain);
+                               s->pricing == 1, chain_wgs, fences, trace, d_snap + h, s->ov_chain);
     }
+    s->chain_nb_last = nb;
     HIP_TRY(hipEventRecord(s->ev_ov_chain[h], s->ov_chain));
     if (max_pivots >= 0 && decided == max_pivots) {  // the budget is spent: this decision can only report the end
       decided += nb;                                 // (LIMIT / UNBOUNDED), there is nothing to sweep
@@ -721,13 +777,12 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
   }
   hipError_t e2 = hipStreamSynchronize(s->stream);
   if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
-  if (rc == 0) dump_chain_trace(s);
   return rc;
 }
 
 // LPSolver.simplex's loop with K pivot decisions per pass over the tableau (bit-identical results).
 static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
-  if (env_int("LPX_CHAIN", 1) != 0 && env_int("LPX_OVERLAP", 1) != 0 && s->row0 == 0 && s->m == s->m_global) {
+  if (s->opt[LPX_OPT_CHAIN] != 0 && s->opt[LPX_OPT_OVERLAP] != 0 && s->row0 == 0 && s->m == s->m_global) {
     // the overlapped form needs a second tableau: a tableau of more than half the HBM keeps the in-place form
     if (s->A2 || ensure_spare_tableau(s) == 0) return blocked_loop_overlapped(s, K, max_pivots);
     (void)hipGetLastError();
@@ -742,15 +797,26 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   LpxCtl* h2 = s->h_snap;
   int64_t decided = 0;  // decisions issued (each either pivots or reports the end)
   // one persistent launch per block (k_block_chain) instead of three launches per decision; LPX_CHAIN=0: off
-  const bool fused = env_int("LPX_CHAIN", 1) != 0 && s->row0 == 0 && s->m == s->m_global;
-  const int chain_wgs = env_int("LPX_CHAIN_WGS", 0);
+  const bool fused = s->opt[LPX_OPT_CHAIN] != 0 && s->row0 == 0 && s->m == s->m_global;
+  // serial form on the handle's own stream: by size, two rows / columns per thread (a grid barrier costs ~1 us at
+  // 32 workgroups, ~4 us at 128), never more than the device holds at once
+  const int64_t work = std::max<int64_t>(s->m, s->B.ld);
+  const int auto_wgs = (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 511) / 512));
+  const int chain_wgs = fused ? clamp_chain_wgs(s, s->opt[LPX_OPT_CHAIN_WGS] > 0 ? (int)s->opt[LPX_OPT_CHAIN_WGS] : auto_wgs,
+                                                device_cus(s))
+                              : 0;
+  const int fences = (int)s->opt[LPX_OPT_CHAIN_FENCES];
+  const bool trace = s->opt[LPX_OPT_CHAIN_TRACE] != 0;
+  s->info.chain_stream_masked = 0;
+  s->info.overlapped = 0;
   LpxCtl* d_snap = nullptr;  // the pinned snapshots as the device sees them
   if (fused) HIP_TRY(hipHostGetDevicePointer((void**)&d_snap, s->h_snap, 0));
   auto issue_block = [&](int slot) -> int {
     const int nb = block_len(K, max_pivots, decided);
     if (fused && nb > 0) {
       lpxk::launch_block_chain(s->B, s->R, s->n, s->m, nb, 0, 0, 0, 1, s->chain_seq++, s->pricing == 1, chain_wgs,
-                               d_snap + slot, s->stream);
+                               fences, trace, d_snap + slot, s->stream);
+      s->chain_nb_last = nb;
     } else {
       for (int k = 0; k < nb; k++) {
         lpxk::launch_block_peek(s->B, s->R, s->n, s->m, s->row0, k, s->d_cand, s->stream);
@@ -779,7 +845,6 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   }
   hipError_t e2 = hipStreamSynchronize(s->stream);
   if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
-  if (rc == 0) dump_chain_trace(s);
   return rc;
 }
 
@@ -818,7 +883,58 @@ extern "C" int lpx_shard_block_sweep(lpx_state* s, int32_t nslots) {
 extern "C" int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep) {
   if (!s || pivots_per_sweep < 0 || pivots_per_sweep > lpxk::kBlockMax)
     return fail(LPX_BAD_ARGUMENT, "lpx_state_set_block: 0 (auto), 1 (off) .. 32");
-  s->block = pivots_per_sweep;
+  s->opt[LPX_OPT_BLOCK] = pivots_per_sweep;
+  return 0;
+}
+
+extern "C" int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value) {
+  if (!s || key < 0 || key >= LPX_OPT_COUNT) return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: unknown option");
+  const OptionSpec& sp = kOptionSpec[key];
+  if (value < sp.lo || value > sp.hi) return fail(LPX_BAD_ARGUMENT, std::string("lpx_state_set_option: value out of range for ") + sp.env);
+  if (key == LPX_OPT_UPDATE_U && value == 3) return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: UPDATE_U is 1, 2 or 4");
+  if (key == LPX_OPT_A2_OFFSET && s->A2) return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: the second tableau exists already");
+  s->opt[key] = value;
+  if (key == LPX_OPT_UPDATE_U || key == LPX_OPT_UPDATE_ROWS || key == LPX_OPT_NT) apply_layout_options(s);
+  return 0;
+}
+
+extern "C" int lpx_state_get_option(const lpx_state* s, int32_t key, int64_t* value) {
+  if (!s || !value || key < 0 || key >= LPX_OPT_COUNT) return fail(LPX_BAD_ARGUMENT, "lpx_state_get_option: bad argument");
+  *value = s->opt[key];
+  return 0;
+}
+
+// Placement census of the last decision launch / blocked sweep: every chain workgroup stores its XCC id + 1, sampled
+// sweep workgroups OR (1 << xcc) into one word (lpx_kernels.hip); folded here, on demand.
+extern "C" int lpx_state_get_info(lpx_state* s, lpx_state_info* out) {
+  if (!s || !out) return fail(LPX_BAD_ARGUMENT, "lpx_state_get_info: NULL argument");
+  HIP_TRY(hipSetDevice(s->device));
+  s->info.block = choose_block(s);
+  s->info.chain_xcd_mask = 0;
+  s->info.sweep_xcd_mask = 0;
+  if (s->R.census) {
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    std::vector<unsigned> h(lpxk::kChainMaxWgs + 2);
+    HIP_TRY(hipMemcpy(h.data(), s->R.census, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+    for (int w = 0; w < s->info.chain_wgs && w < (int)lpxk::kChainMaxWgs; w++)
+      if (h[w]) s->info.chain_xcd_mask |= 1 << ((h[w] - 1) & 15);
+    s->info.sweep_xcd_mask = (int32_t)h[lpxk::kChainMaxWgs];
+  }
+  *out = s->info;
+  return 0;
+}
+
+extern "C" int lpx_state_read_chain_trace(lpx_state* s, int64_t* ticks, int32_t cap, int32_t* ndecisions) {
+  if (!s || !ticks || cap < 0 || !ndecisions) return fail(LPX_BAD_ARGUMENT, "lpx_state_read_chain_trace: bad argument");
+  *ndecisions = 0;
+  if (!s->R.chain_dbg || s->opt[LPX_OPT_CHAIN_TRACE] == 0) return 0;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  long long h[5 * lpxk::kBlockMax];
+  HIP_TRY(hipMemcpy(h, s->R.chain_dbg, sizeof h, hipMemcpyDeviceToHost));
+  const int nd = std::min<int>(std::min<int>(cap, s->chain_nb_last), lpxk::kBlockMax);
+  for (int k = 0; k < 5 * nd; k++) ticks[k] = h[k];
+  *ndecisions = nd;
   return 0;
 }
 
@@ -846,7 +962,7 @@ extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivot
   // batch size: ~1-2 ms of GPU work between host polls
   const double est_us = 16.0 * (double)s->m * (double)s->B.ld / 4.0e6 + 12.0;
   int batch = (int)std::max(1.0, std::min(256.0, 1500.0 / est_us));
-  batch = env_int("LPX_BATCH", batch);
+  if (s->opt[LPX_OPT_BATCH] > 0) batch = (int)s->opt[LPX_OPT_BATCH];
 
   hipEvent_t* evs = s->ev_batch;
   LpxCtl* h2 = s->h_snap;  // two pinned snapshots so that batch k+1 can be in flight while k is inspected

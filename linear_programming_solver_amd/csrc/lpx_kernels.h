@@ -96,7 +96,8 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   double* chain_own_prow;  // kBlockMax x ld: likewise for `prow`
   double* chain_own_dvc;   // kBlockMax x mp: column e_s of the tableau just AFTER pivot s (restart point)
   double* chain_own_b;     // mp: b with all pending pivots applied
-  long long* chain_dbg;    // diagnostics (LPX_CHAIN_TRACE): 5 timestamps per decision of the last block, else NULL
+  long long* chain_dbg;    // diagnostics (LPX_OPT_CHAIN_TRACE): 5 timestamps per decision of the last block
+  unsigned* census;        // [w] = XCC id + 1 of chain workgroup w; [kChainMaxWgs] = OR of (1 << XCC id) of sampled sweep workgroups
 };
 constexpr int kChainMaxWgs = 256;   // <= one workgroup per CU: the whole grid is resident
 // decision number `np` of a block (np pivots pending): candidate record like k_propose's
@@ -109,13 +110,18 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 // not yet reached the tableau (B.A, B.b) this launch reads (n_old pivots; 0: none).  b_from_tableau: first launch
 // of a loop.  seq: launch counter (the two barrier counters alternate).  host_snap: device-visible pointer to a
 // pinned host LpxCtl that receives the loop state when the launch ends.
+// fences: grid-barrier form (bit 0 release fence, bit 1 acquire fence); trace: record phase timestamps in R.chain_dbg.
 void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
-                        int b_from_tableau, int seq, int dantzig, int wgs, LpxCtl* host_snap, hipStream_t s);
+                        int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
+                        hipStream_t s);
+// hipOccupancyMaxActiveBlocksPerMultiprocessor for k_block_chain (256 threads, its static LDS); >= 1
+int chain_blocks_per_cu();
 // apply the valid leading pending pivots (at most K) in one pass
 // A_src / b_src != NULL: out of place — read the tableau and b there, write the updated ones to B.A / B.b
-void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
-                        bool nt, hipStream_t s, const double* A_src = nullptr, const double* b_src = nullptr,
-                        hipEvent_t after_sweep = nullptr);  // after_sweep: recorded between the sweep and the fix-up
+// returns the rows per workgroup used
+int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
+                       bool nt, hipStream_t s, const double* A_src = nullptr, const double* b_src = nullptr,
+                       hipEvent_t after_sweep = nullptr);  // after_sweep: recorded between the sweep and the fix-up
 // phase 1 / restore helpers
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
 void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);

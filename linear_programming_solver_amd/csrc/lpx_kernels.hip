@@ -881,6 +881,12 @@ __device__ __forceinline__ void chain_publish(const LpxCtl* ctl, LpxCtl* host_sn
   __threadfence_system();
 }
 
+__device__ __forceinline__ unsigned xcc_id() {  // which XCD this wave runs on (placement census; never used for correctness)
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 15u;
+}
+
 // Launch parameters.  "own" = the ring half of the block being decided (written here), "old" = the half of the
 // PREVIOUS block when its sweep has not been applied to the tableau this launch reads (n_old pivots; 0 = none):
 // the decisions then see the tableau through n_old + s pending pivots, and that sweep can run beside this launch.
@@ -909,6 +915,7 @@ struct ChainArgs {
   int dantzig, fences;
   LpxCtl* host_snap;
   long long* dbg;
+  unsigned* census;     // [workgroup] = XCC id + 1
 };
 
 __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
@@ -924,7 +931,10 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
   LpxCtl* const ctl = P.ctl;
   const int G = gridDim.x, T = G * 256, tid = threadIdx.x, gid = blockIdx.x * 256 + tid;
   const bool lead = gid == 0;
-  if (tid == 0) sh_fail = 0;
+  if (tid == 0) {
+    sh_fail = 0;
+    if (P.census) P.census[blockIdx.x] = xcc_id() + 1u;
+  }
   if (lead) st_agent(reinterpret_cast<int32_t*>(P.bar_next), 0);
   // loop state at entry: written by earlier launches, identical in every workgroup
   int e = ctl->e_next;
@@ -1261,14 +1271,15 @@ __device__ __forceinline__ int ring_count(const LpxCtl* __restrict__ ring, int k
 }
 
 // The K-fold update of one batch of RB rows x one double2 held in registers; the multipliers come from LDS
-// (one 16-byte broadcast read = two rows).
-template <int K, int RB, bool ALL>
+// (one 16-byte broadcast read = two rows).  PIPE: the steady-state form — straight-line code with the LDS reads of
+// step s+D issued before the arithmetic of step s (the compiler, minimising registers, otherwise puts every read
+// right in front of its use and the wave eats the full LDS latency 2K times per batch — measured: the fp64 VALU then
+// idles half of the time).  Steps s >= np (a partly filled block: the tail of a pivot budget, the end of the LP) are
+// skipped by a wave-uniform scalar branch per step; their read-ahead still runs (sh_col is filled for all K steps).
+template <int K, int RB, bool PIPE>
 __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], const double (*sh_col)[kSweepMaxRows],
                                             int np, int r0) {
-  if constexpr (ALL) {
-    // np == K: straight-line code with the LDS reads of step s+D issued before the arithmetic of step s (the
-    // compiler, minimising registers, otherwise puts every read right in front of its use and the wave eats the
-    // full LDS latency 2K times per batch — measured: the fp64 VALU then idles half of the time).
+  if constexpr (PIPE) {
     constexpr int D = 2;  // read-ahead distance in steps (1, 3 and 4 measured the same or worse)
     d2 cc[D + 1][RB / 2];
 #pragma unroll
@@ -1285,13 +1296,15 @@ __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], cons
               *reinterpret_cast<const d2*>(&sh_col[s + D][(r0 + r) & (kSweepMaxRows - 1)]);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (s < np) {  // wave-uniform
 #pragma unroll
-      for (int r = 0; r < RB; r += 2) {
-        const d2 c2 = cc[s % (D + 1)][r / 2];
-        x[r].x = __dsub_rn(x[r].x, __dmul_rn(c2.x, pr[s].x));                      // LPState.java:162
-        x[r].y = __dsub_rn(x[r].y, __dmul_rn(c2.x, pr[s].y));
-        x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(c2.y, pr[s].x));
-        x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(c2.y, pr[s].y));
+        for (int r = 0; r < RB; r += 2) {
+          const d2 c2 = cc[s % (D + 1)][r / 2];
+          x[r].x = __dsub_rn(x[r].x, __dmul_rn(c2.x, pr[s].x));                      // LPState.java:162
+          x[r].y = __dsub_rn(x[r].y, __dmul_rn(c2.x, pr[s].y));
+          x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(c2.y, pr[s].x));
+          x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(c2.y, pr[s].y));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1320,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
                                                       const double* __restrict__ prow_ring,
                                                       const double* __restrict__ col_ring, int64_t mp,
                                                       const LpxCtl* __restrict__ ring, int kmax,
-                                                      int rows_per_tile, int nstrips) {
+                                                      int rows_per_tile, int nstrips, unsigned* census) {
   __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
   constexpr int RB = (K <= 8) ? 8 : 4;   // rows per batch (register budget: 2K doubles of pivot rows)
@@ -1368,9 +1381,11 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
   const int np = sh_np;
   if (np == 0 && !OOP) return;  // out of place: the tableau still has to be carried over
 
-  // Fast path, the steady state (np == K): straight-line batches without any per-lane guard, software-pipelined
-  // — the next batch's loads are in flight while this one runs its 2K fp64 operations per entry.
-  const int full = (fast_geom && np == K) ? nrows / RB : 0;
+  if (census && (blockIdx.x & 1023) == 0 && threadIdx.x == 0) atomicOr(census, 1u << xcc_id());  // placement sample
+
+  // Fast path, the steady state: straight-line batches without any per-lane guard, software-pipelined — the next
+  // batch's loads are in flight while this one runs its 2 np fp64 operations per entry.
+  const int full = (fast_geom && np > 0) ? nrows / RB : 0;
   if (full > 0) {
 #pragma unroll 1
     for (int bt = 0; bt + 1 < full; ++bt) {
@@ -1706,14 +1721,15 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 // (n_old = 0: no such block, the tableau read is current); seq: launch counter of the loop (barrier counters
 // alternate); B.A / B.b: the tableau version to read.
 void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
-                        int b_from_tableau, int seq, int dantzig, int wgs, LpxCtl* host_snap, hipStream_t s) {
-  // 2 = acquire only: everything that crosses workgroups inside the launch is stored write-through (st_agent), every
-  // wave drains its stores (s_waitcnt vmcnt(0)) and the workgroup meets before its one lane arrives at the counter —
-  // the publish form that needs no release fence.  A release (bit 0: buffer_wbl2) costs ~2 us per barrier AND slows
-  // the sweep running beside the launch (cfg4: 1.99 -> 1.91 ms; cfg3: 39.4k -> 45.7k pivots/s without it).
-  static const int fences = getenv("LPX_CHAIN_FENCES") ? atoi(getenv("LPX_CHAIN_FENCES")) : 2;
+                        int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
+                        hipStream_t s) {
+  // fences = 2 (the engine's default), acquire only: everything that crosses workgroups inside the launch is stored
+  // write-through (st_agent = sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets, ONE lane
+  // arrives with an agent-scope atomic add, the poller's loads of the handed-off bytes are all sc1 loads (ld_agent)
+  // behind a workgroup barrier — the first row of MI355X_MICROARCH.md's table of hand-offs measured valid without
+  // a release — and the acquire is kept on top.  A release (bit 0: buffer_wbl2) writes back the private plain-store
+  // copies (own_col ...) too: ~2 us per barrier AND a slower sweep beside the launch (cfg3: 39.4k vs 45.7k pivots/s).
   const int64_t work = std::max<int64_t>(m, B.ld);
-  // two rows / columns per thread: measured best (a grid barrier costs ~1 us at 32 workgroups, ~4 us at 128)
   int G = wgs > 0 ? wgs : (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 511) / 512));
   G = std::max(1, std::min(G, kChainMaxWgs));
   const int64_t K = kBlockMax;
@@ -1732,8 +1748,18 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   P.bar = R.chain_bar + 32 * (seq & 1); P.bar_next = R.chain_bar + 32 * ((seq + 1) & 1);
   P.hand = reinterpret_cast<unsigned long long*>(R.chain_bar + 64);   // its own 128-byte line
   P.hand_base = (unsigned)(seq + 1) * 64u;  // > any sequence of earlier launches (<= kBlockMax decisions each)
-  P.dantzig = dantzig; P.fences = fences; P.host_snap = host_snap; P.dbg = R.chain_dbg;
+  P.dantzig = dantzig; P.fences = fences; P.host_snap = host_snap; P.dbg = trace ? R.chain_dbg : nullptr;
+  P.census = R.census;
   hipLaunchKernelGGL(k_block_chain, dim3(G), dim3(256), 0, s, P);
+}
+
+int chain_blocks_per_cu() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_block_chain, 256, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    nb = 1;
+  }
+  return std::max(1, nb);
 }
 
 template <int K>
@@ -1744,7 +1770,7 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
   const dim3 grid(nstrips * ntiles), block(256);
 #define LPX_LAUNCH_SWEEP(NT_, OOP_)                                                                              \
   hipLaunchKernelGGL((k_update_multi<K, NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, \
-                     R.mp, R.up, kmax, rows_per_tile, nstrips)
+                     R.mp, R.up, kmax, rows_per_tile, nstrips, R.census ? R.census + kChainMaxWgs : nullptr)
   if (A_src) { if (nt) LPX_LAUNCH_SWEEP(true, true); else LPX_LAUNCH_SWEEP(false, true); }
   else { if (nt) LPX_LAUNCH_SWEEP(true, false); else LPX_LAUNCH_SWEEP(false, false); }
 #undef LPX_LAUNCH_SWEEP
@@ -1754,9 +1780,9 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
 // HBM-bound and 16-row tiles stream best (larger tiles widen the set of DRAM pages in flight: -10 %).  At K = 32
 // it is co-limited by the fp64 VALU, the per-workgroup prologue (2K doubles of pivot rows per thread) weighs more,
 // and 64-row tiles win (+20 % over 16) as long as the grid still has a few thousand workgroups.
-void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
-                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep) {
-  if (K < 1) return;
+int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
+                       bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep) {
+  if (K < 1) return 0;
   if (rows_per_tile <= 0) {
     const int64_t nstrips = (B.ld + 511) / 512;
     rows_per_tile = 16;
@@ -1777,6 +1803,7 @@ void launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
                      R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b);
+  return rows_per_tile;
 }
 
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {

@@ -127,7 +127,7 @@ struct Cleanup {
 // the reference's ArrayIndexOutOfBoundsException), renumber the slots above x0 (:235-244).  c0 = initial.c
 // (already negated for `min`), order = iteration order of initial.coefficients.keySet() or NULL (default names).
 extern "C" int lpx_restore_initial_lp(lpx_state* s, const double* c0, int32_t n, int32_t x0_slot,
-                                      const int32_t* order_in) {
+                                      const int32_t* order_in, int32_t order_len) {
   if (!s || (n > 0 && !c0)) return set_error(LPX_BAD_ARGUMENT, "lpx_restore_initial_lp: NULL argument");
   const int na = get_n(s), m = get_m(s);
   if (na != n + 1 || x0_slot < 0 || x0_slot >= na) return set_error(LPX_BAD_ARGUMENT, "lpx_restore_initial_lp: bad shape/slot");
@@ -139,8 +139,11 @@ extern "C" int lpx_restore_initial_lp(lpx_state* s, const double* c0, int32_t n,
   std::vector<int32_t> slot_of((size_t)n + m + 1, -1);                                // auxLP.coefficients
   for (int sl = 0; sl < na + m; sl++)
     if (perm[sl] >= 0 && perm[sl] <= n + m) slot_of[perm[sl]] = sl;
-  std::vector<int32_t> order(n);
-  if (order_in) order.assign(order_in, order_in + n);
+  // keySet() may hold fewer names than the LP has variables (a named form from getDual() with m > n names only
+  // min(n, m) of them, LPStandardForm.java:139-142): the reference then substitutes only those
+  if (order_in && (order_len < 0 || order_len > n)) return set_error(LPX_BAD_ARGUMENT, "lpx_restore_initial_lp: bad order_len");
+  std::vector<int32_t> order(order_in ? (size_t)order_len : (size_t)n);
+  if (order_in) order.assign(order_in, order_in + order_len);
   else lpx_java_default_name_order(n, order.data());
   std::vector<lpxk::RestoreEntry> ent;
   ent.reserve(n);
@@ -292,7 +295,8 @@ extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, con
     }
     if (status == LPX_OPTIMAL) {
       // restoreInitialLP :200-246
-      status = lpx_restore_initial_lp(s, c0.data(), n, x0, o.restore_order);
+      status = lpx_restore_initial_lp(s, c0.data(), n, x0, o.restore_order,
+                                      o.restore_order ? (o.restore_order_len > 0 ? o.restore_order_len : n) : 0);
       if (status == LPX_DEVICE_ERROR) { res->status = status; return status; }
     }
   }
@@ -322,7 +326,9 @@ extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, con
   if (o.perm_out || o.x_out) {
     std::vector<int32_t> fp((size_t)fn + m);
     if (!fp.empty()) HIP_TRY(hipMemcpy(fp.data(), B.perm, fp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (o.perm_out) memcpy(o.perm_out, fp.data(), fp.size() * sizeof(int32_t));
+    // perm_out is int32[n+m]: a solve that ended inside phase 1 still holds the (n+1)-column auxiliary LP, whose
+    // permutation has n+m+1 entries and numbers x0 — not the caller's problem any more: leave perm_out untouched
+    if (o.perm_out && fn == n) memcpy(o.perm_out, fp.data(), ((size_t)n + m) * sizeof(int32_t));
     if (o.x_out && fn == n) {
       // solution vector (the reference's commented-out printSolution, LPSolver.java:344-374):
       // a basic original variable takes b[row], every nonbasic one is 0

@@ -56,14 +56,11 @@ class LPSolver:
         if restore_order is not None:
             order = np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))
         elif st_form.has_variable_names() and n > 0:
-            # iteration order of initial.coefficients.keySet() (LPSolver.java:213-217): the keys were put
-            # in index order by LPInputReader.processObjective/processConstraint
-            names = [st_form.variables[i] for i in range(n)]
-            key_order = hashmap_key_order(names)
-            order = np.array([st_form.coefficients[k] for k in key_order], dtype=np.int32)
-        if order is not None:
+            order = self._key_set_order(st_form)
+        if order is not None and order.size:
             opts.restore_order = order.ctypes.data_as(_lib.ip)
-        perm = np.zeros(n + m + 1, dtype=np.int32)
+            opts.restore_order_len = int(order.size)
+        perm = np.zeros(n + m, dtype=np.int32)
         x = np.zeros(max(n, 1), dtype=np.float64)
         opts.perm_out = perm.ctypes.data_as(_lib.ip)
         opts.x_out = x.ctypes.data_as(_lib.dp)
@@ -75,6 +72,16 @@ class LPSolver:
         if rc != _lib.OPTIMAL:
             raise_for_status(rc)
         return Decimal(res.objective_text.decode())
+
+    @staticmethod
+    def _key_set_order(form):
+        """Iteration order of `initial.coefficients.keySet()` in restoreInitialLP (LPSolver.java:213-217) as
+        variable indices.  Only the names PRESENT are visited — a named form from getDual() with m > n names
+        just min(n, m) of its variables (LPStandardForm.java:139-142) and the reference substitutes only those.
+        Keys enter the HashMap in index order (LPInputReader.processObjective/processConstraint)."""
+        keys = sorted(form.coefficients, key=lambda k: form.coefficients[k])
+        return np.array([form.coefficients[k] for k in hashmap_key_order(keys)
+                         if 0 <= form.coefficients[k] < form.n], dtype=np.int32)
 
     # ---- the reference's public/package-private helpers around solve() -----------------------------------
     @staticmethod
@@ -155,10 +162,10 @@ class LPSolver:
         if restore_order is not None:
             order = np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))
         elif initial.has_variable_names() and n > 0:
-            names = [initial.variables[i] for i in range(n)]
-            order = np.array([initial.coefficients[k] for k in hashmap_key_order(names)], dtype=np.int32)
+            order = self._key_set_order(initial)
         rc = L.lpx_restore_initial_lp(aux_lp._h, c0.ctypes.data_as(_lib.dp), n, int(index_of_x0),
-                                      None if order is None else order.ctypes.data_as(_lib.ip))
+                                      None if order is None or not order.size else order.ctypes.data_as(_lib.ip),
+                                      0 if order is None else int(order.size))
         if rc:
             raise_for_status(rc)
         aux_lp.n = n                    # names stay keyed by variable id; x0's id simply no longer occurs in perm

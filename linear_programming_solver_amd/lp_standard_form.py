@@ -17,8 +17,11 @@ class LPStandardForm:
         self.m = int(self.b.size if m is None else m)
         self.n = int(self.c.size if n is None else n)
         A = np.asarray(A, dtype=np.float64)
-        self.A = np.ascontiguousarray(A.reshape(self.m, self.n)) if A.size == self.m * self.n \
-            else np.ascontiguousarray(A)
+        if A.size != self.m * self.n:
+            if self.m * self.n != 0:
+                raise ValueError("LPStandardForm: A has %d entries, expected m*n = %d*%d" % (A.size, self.m, self.n))
+            A = np.zeros((self.m, self.n))
+        self.A = np.ascontiguousarray(A.reshape(self.m, self.n))
         self.variables = None if variables is None else dict(variables)
         self.coefficients = None if coefficients is None else dict(coefficients)
         self.maximize = bool(maximize)

@@ -11,7 +11,7 @@ from .errors import raise_for_status
 
 class LPState:
     def __init__(self, A, b, c, v=0.0, variables=None, coefficients=None, m=None, n=None, device=0,
-                 perm=None, row0=0, m_global=None, pricing="reference", block=None):
+                 perm=None, row0=0, m_global=None, pricing="reference", block=None, options=None):
         """new LPState(A, b, c, v, variables, coefficients, m, n)  (LPState.java:101-112).
         `variables`/`coefficients` are the reference's name maps (slot -> name / name -> slot); they are
         kept on the host and permuted from the device's slot permutation on demand."""
@@ -21,7 +21,11 @@ class LPState:
         self.m = int(b.size if m is None else m)
         self.n = int(c.size if n is None else n)
         A = np.ascontiguousarray(np.asarray(A, dtype=np.float64))
-        A = A.reshape(self.m, self.n) if A.size == self.m * self.n else np.zeros((self.m, self.n))
+        if A.size != self.m * self.n:
+            if self.m * self.n != 0:    # the C ABI answers LPX_BAD_ARGUMENT to a short array; so does the wrapper
+                raise ValueError("LPState: A has %d entries, expected m*n = %d*%d" % (A.size, self.m, self.n))
+            A = np.zeros((self.m, self.n))
+        A = A.reshape(self.m, self.n)
         self.row0 = int(row0)
         self.m_global = int(self.m if m_global is None else m_global)
         p = None if perm is None else np.ascontiguousarray(np.asarray(perm, dtype=np.int32))
@@ -43,10 +47,12 @@ class LPState:
             if rc:
                 raise_for_status(rc)
 
-        if block is not None:          # pivots per sweep of the device loop: None/0 = by size, 1 = off, 2..16
+        if block is not None:          # pivots per sweep of the device loop: None/0 = by size, 1 = off, 2..32
             rc = L.lpx_state_set_block(h, int(block))
             if rc:
                 raise_for_status(rc)
+        for key, value in (options or {}).items():
+            self.set_option(key, value)
 
     # -- lifecycle
     def close(self):
@@ -142,6 +148,38 @@ class LPState:
     def coefficients(self):
         v = self.variables
         return None if v is None else {name: s for s, name in v.items()}
+
+    def set_option(self, key, value):
+        """lpx_state_set_option: tuning / diagnostic option of this handle (names: _lib.OPTIONS)."""
+        rc = self._L.lpx_state_set_option(self._h, _lib.OPTIONS[key] if isinstance(key, str) else int(key), int(value))
+        if rc:
+            raise_for_status(rc)
+
+    def get_option(self, key):
+        v = C.c_int64()
+        rc = self._L.lpx_state_get_option(self._h, _lib.OPTIONS[key] if isinstance(key, str) else int(key), C.byref(v))
+        if rc:
+            raise_for_status(rc)
+        return v.value
+
+    def info(self):
+        """lpx_state_get_info as a dict: what the last loop actually did (block, decision-kernel grid and its
+        residency bound, whether the CU-masked streams exist, which XCDs the kernels ran on)."""
+        out = _lib.StateInfo()
+        rc = self._L.lpx_state_get_info(self._h, C.byref(out))
+        if rc:
+            raise_for_status(rc)
+        return {k: getattr(out, k) for k, _ in _lib.StateInfo._fields_ if k != "reserved"}
+
+    def chain_trace(self):
+        """Phase timestamps (100 MHz ticks) of the last decision launch: array [decisions, 5]; needs option
+        chain_trace = 1 before the loop."""
+        buf = np.zeros(5 * 32, dtype=np.int64)
+        nd = C.c_int32()
+        rc = self._L.lpx_state_read_chain_trace(self._h, buf.ctypes.data_as(_lib.i64p), 32, C.byref(nd))
+        if rc:
+            raise_for_status(rc)
+        return buf[: 5 * nd.value].reshape(nd.value, 5)
 
     def block(self):
         """Pivots per sweep in effect for the device loop (1 = one update pass per pivot)."""

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lpxlib):
     for name in names:
         assert hasattr(L, name), "liblpx.so does not export " + name
         assert name in bound, "python binding misses " + name
-    assert L.lpx_abi_version() == 1
+    assert L.lpx_abi_version() == 2
 
 
 def test_status_messages_match_reference_text(lpxlib):
@@ -104,15 +104,25 @@ def test_python_struct_layouts_match_the_header(tmp_path):
 #include <stddef.h>
 #include "lpx.h"
 int main(void){
-  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(lpx_solve_result), offsetof(lpx_solve_result, objective_text),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(lpx_solve_result), offsetof(lpx_solve_result, objective_text),
          offsetof(lpx_solve_result, pivots_phase1), offsetof(lpx_solve_result, seconds_pivots),
-         sizeof(lpx_solve_options), offsetof(lpx_solve_options, keep_state));
+         sizeof(lpx_solve_options), offsetof(lpx_solve_options, keep_state),
+         offsetof(lpx_solve_options, restore_order_len), sizeof(lpx_state_info), offsetof(lpx_state_info, sweep_rows));
   return 0; }
 ''')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     from linear_programming_solver_amd import _lib
-    R, O = _lib.SolveResult, _lib.SolveOptions
+    R, O, I = _lib.SolveResult, _lib.SolveOptions, _lib.StateInfo
     assert got == [C.sizeof(R), R.objective_text.offset, R.pivots_phase1.offset, R.seconds_pivots.offset,
-                   C.sizeof(O), O.keep_state.offset]
+                   C.sizeof(O), O.keep_state.offset, O.restore_order_len.offset, C.sizeof(I), I.sweep_rows.offset]
+
+
+def test_option_keys_match_the_header():
+    """_lib.OPTIONS mirrors enum lpx_option."""
+    from linear_programming_solver_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lpx.h")).read(), flags=re.S)
+    enum = dict((name.lower(), int(val)) for name, val in re.findall(r"LPX_OPT_([A-Z0-9_]+) = (\d+)", text))
+    count = enum.pop("count")
+    assert enum == _lib.OPTIONS and count == len(enum)

@@ -727,21 +727,23 @@ def test_blocked_pivoting_is_bit_identical(lps, oracle, shape, block):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"LPX_OVERLAP": "0"},                              # k_block_chain, then the in-place sweep, one after the other
-    {"LPX_CHAIN": "0"},                                # three launches per decision (the form the shards use)
-    {"LPX_OVERLAP_SERIAL": "1"},                       # out-of-place sweeps without concurrency
-    {"LPX_OVERLAP_MASK": "0"},                         # decisions beside the sweep without CU masks
-    {"LPX_CHAIN_WGS": "1"}, {"LPX_CHAIN_WGS": "3"},    # several rows / columns per thread in k_block_chain
-    {"LPX_CHAIN_WGS": "7", "LPX_OVERLAP": "0"},
+    {"overlap": 0},                              # k_block_chain, then the in-place sweep, one after the other
+    {"chain": 0},                                # three launches per decision (the form the shards use)
+    {"overlap_serial": 1},                       # out-of-place sweeps without concurrency
+    {"overlap_mask": 0},                         # decisions beside the sweep without CU masks
+    {"chain_wgs": 1}, {"chain_wgs": 3},          # several rows / columns per thread in k_block_chain
+    {"chain_wgs": 7, "overlap": 0},
+    {"chain_fences": 3},                         # release + acquire at every grid barrier (the conservative form)
+    {"sweep_rows": 8}, {"sweep_rows": 128},
 ], ids=lambda k: ",".join("%s=%s" % kv for kv in sorted(k.items())))
-def test_blocked_loop_forms_are_bit_identical(lps, oracle, knobs, monkeypatch):
+def test_blocked_loop_forms_are_bit_identical(lps, oracle, knobs):
     """Every form of the blocked loop (default: decisions one block ahead of out-of-place sweeps) gives the
-    one-pass-per-pivot result bit for bit; the library reads these diagnostic knobs at every call."""
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+    one-pass-per-pivot result bit for bit; the forms are selected through the handle (lpx_state_set_option)."""
     for (m, n), block in (((300, 700), 32), ((1100, 260), 16), ((64, 2100), 8)):
         A, b, c = dense_lp(m, n, seed=7 * m + n)
-        st = lps.LPState(A, b, c, block=block)
+        st = lps.LPState(A, b, c, block=block, options=knobs)
+        for k, v in knobs.items():
+            assert st.get_option(k) == v
         ref = oracle.State(A, b, c, kind=oracle.FP64)
         for budget in (block, 2 * block + 3, 5 * block, 1, -1):
             status, pivots, _ = st.simplex_loop(max_pivots=budget)
@@ -749,6 +751,155 @@ def test_blocked_loop_forms_are_bit_identical(lps, oracle, knobs, monkeypatch):
             assert (status, pivots) == (want["status"], want["pivots"]), (knobs, m, n, block, budget)
             assert_state_bits_equal(st.read(), ref.read(), "%s block %d budget %d" % (knobs, block, budget))
         st.close()
+
+
+def test_option_validation(lps):
+    st = lps.LPState([[1.0, 2.0]], [1.0], [1.0, 1.0])
+    with pytest.raises(ValueError):
+        st.set_option("chain_fences", 7)
+    with pytest.raises(ValueError):
+        st.set_option(99, 0)
+    with pytest.raises(ValueError):
+        st.set_option("update_u", 3)
+    st.set_option("block", 4)
+    assert st.block() == 4 and st.get_option("block") == 4
+    st.close()
+    with pytest.raises(ValueError):
+        lps.LPState(np.ones((3, 2)), [1.0, 1.0], [1.0, 1.0])      # wrong-shaped A is an error, not a zero tableau
+
+
+def _timed_form_vs_oracle(lps, oracle, m, n, budgets, options=None, threads=16):
+    """The loop form bench.py times (default options: blocks of 32 decisions in the persistent decision kernel, one
+    block ahead of out-of-place non-temporal sweeps) against the fp64 oracle at full size: status, pivot count, v,
+    perm, b, c bit for bit and the position-keyed checksum of A (host side in row chunks)."""
+    import bench
+    from linear_programming_solver_amd.lp_state import checksum_host
+    A, b, c = bench.gen_rows(m, n, 1, 0, m)
+    st = lps.LPState(A, b, c, options=options)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    del A
+    for budget in budgets:
+        status, pivots, _ = st.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget, threads=threads)
+        assert (status, pivots) == (want["status"], want["pivots"]) == (9, budget)
+        wA, wb, wc, wv, wperm = ref.read()
+        _, gb, gc, gv, gperm = st.read(want_A=False)
+        assert gv == wv and list(gperm) == list(wperm), budget
+        assert np.array_equal(bits(gb), bits(wb)) and np.array_equal(bits(gc), bits(wc)), budget
+        mask = (1 << 64) - 1
+        sa = 0
+        for r0 in range(0, m, 2048):
+            sa = (sa + checksum_host(wA[r0:r0 + 2048], wb[:0], wc[:0], row0=r0)[0]) & mask
+        del wA
+        assert st.checksum()[0] == sa, "tableau differs from the oracle after a budget of %d" % budget
+    info = st.info()
+    st.close()
+    ref.close()
+    return info
+
+
+def test_cfg3_timed_form_200_pivots_vs_fp64_oracle(lps, oracle):
+    """BASELINE cfg3 (8192 x 16384): 70 + 200 pivots through the default loop — full K = 32 blocks, the wide
+    decision kernel beside the sweeps, a budget tail folded into the last block."""
+    info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (70, 200))
+    assert info["block"] == 32 and info["overlapped"] == 1
+    assert info["chain_wgs"] <= info["chain_resident_max"]
+    print("cfg3 placement:", info)
+
+
+def test_cfg4_timed_form_70_pivots_vs_fp64_oracle(lps, oracle):
+    """BASELINE cfg4 (32768 x 16384, 4 GiB): two full K = 32 blocks + a tail through the default loop, then 25 more
+    (the driver's bench command is 5 + 20 pivots), every time against the fp64 oracle."""
+    info = _timed_form_vs_oracle(lps, oracle, 32768, 16384, (70, 25))
+    assert info["block"] == 32 and info["overlapped"] == 1 and info["nontemporal"] == 1
+    assert info["chain_wgs"] <= info["chain_resident_max"]
+    print("cfg4 placement:", info)
+
+
+@pytest.mark.parametrize("shape", [(2048, 4096), (4096, 8192), (8192, 2048)])
+@pytest.mark.parametrize("fences", [2, 3])
+def test_wide_decision_kernel_vs_oracle(lps, oracle, shape, fences):
+    """The decision kernel at full width (33 workgroups requested, clamped to what is resident) on 2-8 k-row
+    shapes, block 32, beside the sweeps: workgroup 0's one-way hand-off and the grid barrier run wide against
+    the oracle, in both barrier forms (acquire-only default, release + acquire)."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=3 * m + n)
+    st = lps.LPState(A, b, c, block=32, options={"chain_wgs": 33, "chain_fences": fences})
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (96, 45, 160):
+        status, pivots, _ = st.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget, threads=16)
+        assert (status, pivots) == (want["status"], want["pivots"]), (shape, fences, budget)
+        assert_state_bits_equal(st.read(), ref.read(), "%s fences %d budget %d" % (shape, fences, budget))
+    info = st.info()
+    assert 8 <= info["chain_wgs"] <= min(33, info["chain_resident_max"]), info
+    st.close()
+
+
+def test_decision_kernel_residency_is_bounded(lps):
+    """lpx_state_get_info: the decision kernel's grid never exceeds what the CUs of its stream hold at once (its
+    workgroups spin at grid barriers), whatever is requested; the placement census names the XCDs it ran on."""
+    A, b, c = dense_lp(1024, 2048, seed=5)
+    for masked in (1, 0):
+        st = lps.LPState(A, b, c, block=16, options={"chain_wgs": 256, "overlap_mask": masked, "chain_trace": 1})
+        status, pivots, _ = st.simplex_loop(max_pivots=40)
+        assert (status, pivots) == (9, 40)
+        info = st.info()
+        assert info["chain_wgs_requested"] == 256
+        assert info["chain_wgs"] == min(256, info["chain_resident_max"]) and info["chain_blocks_per_cu"] >= 1
+        assert info["chain_xcd_mask"] != 0
+        if info["chain_stream_masked"]:
+            assert info["chain_resident_max"] == info["chain_blocks_per_cu"] * 32
+        tr = st.chain_trace()
+        assert tr.shape[1] == 5 and tr.shape[0] >= 1 and np.all(np.diff(tr[0]) >= 0)
+        st.close()
+
+
+def test_solve_infeasible_with_exactly_sized_perm_out(lps):
+    """lpx_solve on an LP that ends inside phase 1 must not write past perm_out's n+m entries (the auxiliary LP's
+    permutation has n+m+1)."""
+    import ctypes as C
+    from linear_programming_solver_amd import _lib
+    L = _lib.lib()
+    A = np.array([[1.0, 1.0], [-1.0, -1.0]])
+    b = np.array([1.0, -3.0])         # x1 + x2 <= 1 and x1 + x2 >= 3: infeasible
+    c = np.array([1.0, 1.0])
+    m, n = 2, 2
+    guard = np.full(n + m + 8, 0x5A5A5A5A, dtype=np.int32)
+    opts = _lib.SolveOptions()
+    opts.max_pivots = -1
+    opts.perm_out = guard.ctypes.data_as(_lib.ip)
+    res = _lib.SolveResult()
+    rc = L.lpx_solve(m, n, A.ctypes.data_as(_lib.dp), n, b.ctypes.data_as(_lib.dp), c.ctypes.data_as(_lib.dp), 1,
+                     C.byref(opts), C.byref(res))
+    assert rc == _lib.INFEASIBLE and res.phase1_used == 1
+    assert np.all(guard[n + m:] == 0x5A5A5A5A), guard
+    # and a solve that reaches phase 2 fills exactly n+m entries
+    b2 = np.array([4.0, -1.0])
+    guard[:] = 0x5A5A5A5A
+    rc = L.lpx_solve(m, n, A.ctypes.data_as(_lib.dp), n, b2.ctypes.data_as(_lib.dp), c.ctypes.data_as(_lib.dp), 1,
+                     C.byref(opts), C.byref(res))
+    assert rc == _lib.OPTIMAL and res.phase1_used == 1
+    assert sorted(guard[: n + m].tolist()) == list(range(n + m)) and np.all(guard[n + m:] == 0x5A5A5A5A)
+
+
+def test_solve_named_dual_with_more_variables_than_names(lps, oracle):
+    """solve(getDual()) of a named form with m > n: the reference's getDual names only n of the dual's m variables
+    (LPStandardForm.java:139-142); restoreInitialLP then visits only the named ones."""
+    A = np.array([[1.0, 2.0], [3.0, 1.0], [1.0, 1.0]])          # m = 3 > n = 2
+    form = lps.LPStandardForm(A, [4.0, 5.0, 3.0], [1.0, 1.0], {0: "x1", 1: "x2"}, {"x1": 0, "x2": 1}, maximize=True)
+    dual = form.get_dual()
+    assert dual.n == 3 and len(dual.coefficients) == 2
+    solver = lps.LPSolver()
+    ans = solver.solve(dual)          # min 4 y1 + 5 y2 + 3 y3, A^T y <= c -> needs phase 1? (b = c >= 0: no)
+    res, _ = oracle.solve(dual.A, dual.b, dual.c, dual.maximize, kind=oracle.FP64, want_trace=False)
+    assert str(ans) == res["objective_text"]
+    # with a negative right-hand side phase 1 runs and the keySet() order has 2 entries for 3 variables
+    dual2 = lps.LPStandardForm(dual.A, [1.0, -1.0], dual.c, dual.variables, dual.coefficients, maximize=True)
+    try:
+        solver.solve(dual2)
+    except Exception as ex:           # whatever the outcome, it must be a solver outcome, not a KeyError
+        assert not isinstance(ex, KeyError), ex
 
 
 def test_blocked_loop_many_blocks_and_dantzig(lps, oracle):
