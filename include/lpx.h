@@ -86,11 +86,13 @@ void lpx_state_destroy(lpx_state* s);
 /* Issue all further device work of this handle on `hip_stream` (a hipStream_t; NULL = the handle's own). */
 int lpx_state_set_stream(lpx_state* s, void* hip_stream);
 
-/* Replace the handle's own stream by one whose CU mask leaves `reserve_xcds` (0..4) whole XCDs (32 CUs each)
- * to OTHER streams, and make it the handle's stream.  The row update is HBM-bound and keeps its full rate on 7
- * XCDs; the reserved XCD guarantees that a collective or a decision kernel issued on another stream runs
- * beside it (look-ahead pipeline).  *stream_out receives the hipStream_t (wrap it, e.g. torch ExternalStream). */
-int lpx_state_use_masked_stream(lpx_state* s, int32_t reserve_xcds, void** stream_out);
+/* Replace the handle's own stream by one whose CU mask leaves 32 * reserve_units (0..4) CUs to OTHER streams — the
+ * same 4 * reserve_units CUs on every one of the 8 XCDs (a mask cannot exclude a whole XCD on MI355X: an XCD whose
+ * mask bits are all clear runs unmasked) — and make it the handle's stream.  The row update is HBM-bound and keeps
+ * its rate on the remaining CUs; the reserved ones guarantee that a collective or a decision kernel issued on
+ * another stream runs beside it (look-ahead pipeline).  *stream_out receives the hipStream_t (wrap it, e.g. torch
+ * ExternalStream). */
+int lpx_state_use_masked_stream(lpx_state* s, int32_t reserve_units, void** stream_out);
 
 /* Entering rule of this handle.  0 (default) = the reference's rule: first slot with c[j] > 1e-9
  * (LPState.java:274-285).  1 = Dantzig: largest c[j], lowest slot on ties — an OPT-IN extension of this
@@ -122,7 +124,7 @@ typedef enum lpx_option {
   LPX_OPT_CHAIN = 1,          /* 1 = all decisions of a block in one persistent launch (default); 0 = three launches */
   LPX_OPT_OVERLAP = 2,        /* 1 = decisions of block k+1 beside the sweep of block k (default); 0 = serial        */
   LPX_OPT_OVERLAP_SERIAL = 3, /* 1 = the overlapped loop's kernels and buffers without concurrency (diagnostics)     */
-  LPX_OPT_OVERLAP_MASK = 4,   /* 1 = CU-masked streams: one XCD for the decisions, seven for the sweep (default)     */
+  LPX_OPT_OVERLAP_MASK = 4,   /* 1 = CU-masked streams: 4 CUs of every XCD for the decisions, the rest for the sweep  */
   LPX_OPT_CHAIN_WGS = 5,      /* workgroups of the decision kernel; 0 = by size; always clamped to what is resident  */
   LPX_OPT_CHAIN_FENCES = 6,   /* grid barrier of the decision kernel: bit 0 release fence, bit 1 acquire fence       */
   LPX_OPT_SWEEP_ROWS = 7,     /* rows per workgroup of the blocked sweep; 0 = by size                                */

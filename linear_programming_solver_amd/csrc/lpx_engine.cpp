@@ -648,15 +648,20 @@ static lpxk::BlockRing ring_half(const lpx_state* s, int h) {
   return R;
 }
 
-// One XCD for the decisions, seven for the sweep (CU i belongs to XCD i % 8, see lpx_state_use_masked_stream).
+// CU masks on MI355X (measured, scripts/micro/cu_mask.hip -> profiles/r02_cu_mask.txt): mask bit i names CU i / 8 of
+// XCD i % 8, and an XCD whose bits are ALL clear is not excluded — it runs unmasked.  So a stream cannot be kept off
+// an XCD; what a mask can do is reserve the same few CUs on every XCD.  The decisions get the last kChainCusPerXcd CUs
+// of each XCD (one resident workgroup each), the sweep the others: the two kernels never wait for each other's CUs.
+static constexpr int kChainCusPerXcd = 4;
 static int ensure_overlap_streams(lpx_state* s) {
   if (s->ov_chain) return 0;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));
   const int ncu = prop.multiProcessorCount;
+  const int per_xcd = ncu / 8;
   std::vector<uint32_t> m_sweep((ncu + 31) / 32, 0u), m_chain((ncu + 31) / 32, 0u);
   for (int cu = 0; cu < ncu; cu++) {
-    if ((cu % 8) == 7) m_chain[cu / 32] |= 1u << (cu % 32);
+    if (cu / 8 >= per_xcd - kChainCusPerXcd) m_chain[cu / 32] |= 1u << (cu % 32);
     else m_sweep[cu / 32] |= 1u << (cu % 32);
   }
   bool masked = false;
@@ -676,7 +681,7 @@ static int ensure_overlap_streams(lpx_state* s) {
     HIP_TRY(hipStreamCreateWithFlags(&s->ov_sweep, hipStreamNonBlocking));
   }
   s->ov_masked = masked;
-  s->ov_chain_cus = masked ? ncu / 8 : ncu;
+  s->ov_chain_cus = masked ? 8 * kChainCusPerXcd : ncu;
   for (int k = 0; k < 2; k++) {
     HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_chain[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_sweep[k], hipEventDisableTiming));
@@ -824,8 +829,9 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
         if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, false, s->stream);
       }
     }
+    const bool probe_only = max_pivots >= 0 && decided == max_pivots;  // can only report the end: nothing to sweep
     decided += nb;
-    if (nb > 0) {
+    if (nb > 0 && !probe_only) {
       if (int rc = launch_sweep_profiled(s, nb)) return rc;
     }
     if (!(fused && nb > 0))  // the fused launch writes the snapshot itself
@@ -1037,9 +1043,9 @@ extern "C" int lpx_shard_probe(lpx_state* s, const double* d_gathered, int32_t n
   return 0;
 }
 
-// Measured on MI355X (cfg3, profiles/r01_cu_mask.log): with the CU-mask bits of ONE whole XCD cleared (bit i
-// belongs to XCD i % 8) the HBM-bound row update keeps its full 6.3 TB/s on the remaining 7 XCDs, while
-// clearing a few CUs of one XCD slows it down (the round-robin workgroup dealer then waits for that XCD).
+// A CU mask cannot keep a stream off an XCD (an XCD whose bits are all clear runs unmasked: profiles/r02_cu_mask.txt),
+// so "reserve_xcds" reserves one XCD's WORTH of CUs — 32 — as the same 4 CUs on each of the 8 XCDs, per unit.  The
+// HBM-bound row update keeps its rate on the remaining CUs; kernels of other streams find the reserved ones free.
 extern "C" int lpx_state_use_masked_stream(lpx_state* s, int32_t reserve_xcds, void** stream_out) {
   if (!s || reserve_xcds < 0 || reserve_xcds > 4) return fail(LPX_BAD_ARGUMENT, "lpx_state_use_masked_stream: bad argument");
   HIP_TRY(hipSetDevice(s->device));
@@ -1053,8 +1059,9 @@ extern "C" int lpx_state_use_masked_stream(lpx_state* s, int32_t reserve_xcds, v
     const int ncu = prop.multiProcessorCount;
     std::vector<uint32_t> mask((ncu + 31) / 32, 0xFFFFFFFFu);
     if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1u;
-    for (int cu = 0; cu < ncu; cu++)
-      if ((cu % 8) >= 8 - reserve_xcds) mask[cu / 32] &= ~(1u << (cu % 32));
+    const int per_xcd = ncu / 8;
+    for (int cu = 0; cu < ncu; cu++)  // bit i = CU i / 8 of XCD i % 8: clear the last 4 * reserve_xcds CUs of EVERY XCD
+      if (cu / 8 >= per_xcd - 4 * reserve_xcds) mask[cu / 32] &= ~(1u << (cu % 32));
     HIP_TRY(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
   }
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);

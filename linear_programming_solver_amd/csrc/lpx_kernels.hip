@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace lpxk {
 
@@ -1274,12 +1275,14 @@ __device__ __forceinline__ int ring_count(const LpxCtl* __restrict__ ring, int k
 // (one 16-byte broadcast read = two rows).  PIPE: the steady-state form — straight-line code with the LDS reads of
 // step s+D issued before the arithmetic of step s (the compiler, minimising registers, otherwise puts every read
 // right in front of its use and the wave eats the full LDS latency 2K times per batch — measured: the fp64 VALU then
-// idles half of the time).  Steps s >= np (a partly filled block: the tail of a pivot budget, the end of the LP) are
-// skipped by a wave-uniform scalar branch per step; their read-ahead still runs (sh_col is filled for all K steps).
-template <int K, int RB, bool PIPE>
+// idles half of the time).  In a partly filled block (the tail of a pivot budget, the end of the LP) the steps
+// s >= np are skipped by a wave-uniform scalar branch per step; their read-ahead still runs (sh_col is filled for all
+// K steps).
+enum SweepMode { kSweepSimple = 0, kSweepAll = 1, kSweepGuarded = 2 };
+template <int K, int RB, int MODE>
 __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], const double (*sh_col)[kSweepMaxRows],
                                             int np, int r0) {
-  if constexpr (PIPE) {
+  if constexpr (MODE != kSweepSimple) {
     constexpr int D = 2;  // read-ahead distance in steps (1, 3 and 4 measured the same or worse)
     d2 cc[D + 1][RB / 2];
 #pragma unroll
@@ -1296,7 +1299,9 @@ __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], cons
               *reinterpret_cast<const d2*>(&sh_col[s + D][(r0 + r) & (kSweepMaxRows - 1)]);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (s < np) {  // wave-uniform
+      // kSweepAll (np == K, the steady state): no branch at all — 32 scalar branches per batch cost 17 % (cfg4 alone
+      // in place: 1.64 ms vs 1.91 ms); kSweepGuarded: a wave-uniform branch per step for partly filled blocks
+      if (MODE == kSweepAll || s < np) {
 #pragma unroll
         for (int r = 0; r < RB; r += 2) {
           const d2 c2 = cc[s % (D + 1)][r / 2];
@@ -1381,12 +1386,13 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
   const int np = sh_np;
   if (np == 0 && !OOP) return;  // out of place: the tableau still has to be carried over
 
-  if (census && (blockIdx.x & 1023) == 0 && threadIdx.x == 0) atomicOr(census, 1u << xcc_id());  // placement sample
+  if (census && blockIdx.x % 509u == 0 && threadIdx.x == 0) atomicOr(census, 1u << xcc_id());  // placement sample
 
   // Fast path, the steady state: straight-line batches without any per-lane guard, software-pipelined — the next
   // batch's loads are in flight while this one runs its 2 np fp64 operations per entry.
   const int full = (fast_geom && np > 0) ? nrows / RB : 0;
-  if (full > 0) {
+  auto stream_batches = [&](auto mode) {
+    constexpr int MODE = decltype(mode)::value;
 #pragma unroll 1
     for (int bt = 0; bt + 1 < full; ++bt) {
       const int r0 = bt * RB;
@@ -1395,7 +1401,7 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
         const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(r0 + RB + r) * row_bytes));
         xn[r] = NT ? __builtin_nontemporal_load(q) : *q;
       }
-      sweep_apply<K, RB, true>(x, pr, sh_col, np, r0);
+      sweep_apply<K, RB, MODE>(x, pr, sh_col, np, r0);
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
@@ -1406,13 +1412,17 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
     }
     {  // last full batch: nothing left to prefetch
       const int r0 = (full - 1) * RB;
-      sweep_apply<K, RB, true>(x, pr, sh_col, np, r0);
+      sweep_apply<K, RB, MODE>(x, pr, sh_col, np, r0);
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
         if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
       }
     }
+  };
+  if (full > 0) {
+    if (np == K) stream_batches(std::integral_constant<int, kSweepAll>{});
+    else stream_batches(std::integral_constant<int, kSweepGuarded>{});
   }
   // the rest (partial blocks, rows beyond the last full batch, the partial last strip): guarded
   for (int r0 = full * RB; r0 < nrows; r0 += RB) {
@@ -1425,7 +1435,7 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
         y[r] = NT ? __builtin_nontemporal_load(q) : *q;
       }
     }
-    sweep_apply<K, RB, false>(y, pr, sh_col, np, r0);
+    sweep_apply<K, RB, kSweepSimple>(y, pr, sh_col, np, r0);
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       if (r0 + r < nrows && act) {

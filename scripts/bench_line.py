@@ -5,5 +5,13 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 j = json.loads(sys.stdin.read())
 r = j["roofline"]
+par = j.get("parity_after_timed_region") or {}
 print(tag, round(j["value"], 1), "pivots/s; K", j["config"].get("pivots_per_sweep"), "sweep",
-      round(r["avg_kernel_ms"] * 1e3, 1), "us x", r["launches_sampled"], "obj", j["objective_after_timed_region"])
+      round((r.get("avg_kernel_ms") or 0) * 1e3, 1), "us x", r["launches_sampled"], "bound", r["bound"], "frac",
+      None if r["frac"] is None else round(r["frac"], 3), "parity", par.get("ok", par.get("reason")),
+      "engine", j.get("engine"))
+if "cfg3" in j:
+    r3 = j["cfg3"]["roofline"]
+    print(tag, "cfg3", round(j["cfg3"]["value"], 1), "pivots/s sweep", round((r3.get("avg_kernel_ms") or 0) * 1e3, 1),
+          "us frac", None if r3["frac"] is None else round(r3["frac"], 3), "parity",
+          (j["cfg3"].get("parity_after_timed_region") or {}).get("ok"))
