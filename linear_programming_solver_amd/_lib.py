@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblpx.so")
+# LPX_LIB_PATH: kernel-variant experiments of scripts/ load another build of the same library (still no fallback)
+LIB_PATH = os.environ.get("LPX_LIB_PATH") or os.path.join(_HERE, "liblpx.so")
 
 # lpx_status (include/lpx.h)
 OPTIMAL, UNBOUNDED, INFEASIBLE, AUX_UNBOUNDED, NO_DEGENERATE_PIVOT, BAD_ARGUMENT, RESTORE_INDEX_FAULT, \

@@ -1257,6 +1257,9 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
 // (cfg4: 1.36 ms for one pass, 1.55 ms at K = 16, 2.4 ms at K = 32; a one-double-per-thread variant with
 // twice the occupancy was not faster).
 constexpr int kSweepMaxRows = 128;
+#ifndef LPX_SWEEP_NBUF
+#define LPX_SWEEP_NBUF 2   // register buffers of the sweep: batches in flight = NBUF - 1 (3: measured 4 % slower)
+#endif
 
 // Number of valid leading pending pivots (slots >= kmax were not decided this block): one parallel look at the
 // ring by the first wave instead of a chain of dependent loads.  Result valid in every thread.
@@ -1341,7 +1344,8 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
                                                       int rows_per_tile, int nstrips, unsigned* census) {
   __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
-  constexpr int RB = (K <= 8) ? 8 : 4;   // rows per batch (register budget: 2K doubles of pivot rows)
+  // rows per batch (register budget: 2K doubles of pivot rows); K = 32 with 8 rows measured 13 % slower (r02)
+  constexpr int RB = (K <= 8) ? 8 : 4;
   const int strip = blockIdx.x % nstrips;
   const int tile = blockIdx.x / nstrips;
   const int cj = strip * 512 + 2 * threadIdx.x;
@@ -1369,13 +1373,20 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
     pr[s] = act ? *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj) : d2{0.0, 0.0};
   // Full strips (all but possibly the last one of a row) with at least one full batch take the fast path below.
   const bool fast_geom = (strip + 1) * 512 <= (int)ld && nrows >= RB;
-  d2 x[RB], xn[RB];
+  // NB register buffers of RB rows each: while one batch is computed, the next NB-1 are in flight (the kernel's time
+  // was T_hbm + ~0.55 T_valu with one batch ahead: too few bytes in flight to keep HBM busy during the fp64 work)
+  constexpr int NB = (K >= 32) ? LPX_SWEEP_NBUF : 2;  // K = 16: a third buffer would cost the third wave per SIMD
+  const int nfull_geom = fast_geom ? nrows / RB : 0;
+  d2 xb[NB][RB];
 #pragma unroll
-  for (int r = 0; r < RB; ++r) {
-    x[r] = d2{0.0, 0.0};
-    if (fast_geom) {  // uniform
-      const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)r * row_bytes));
-      x[r] = NT ? __builtin_nontemporal_load(q) : *q;
+  for (int u = 0; u + 1 < NB; ++u) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      xb[u][r] = d2{0.0, 0.0};
+      if (u < nfull_geom) {  // uniform
+        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(u * RB + r) * row_bytes));
+        xb[u][r] = NT ? __builtin_nontemporal_load(q) : *q;
+      }
     }
   }
   if (threadIdx.x < 64) {
@@ -1390,33 +1401,29 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
 
   // Fast path, the steady state: straight-line batches without any per-lane guard, software-pipelined — the next
   // batch's loads are in flight while this one runs its 2 np fp64 operations per entry.
-  const int full = (fast_geom && np > 0) ? nrows / RB : 0;
+  const int full = np > 0 ? nfull_geom : 0;
   auto stream_batches = [&](auto mode) {
     constexpr int MODE = decltype(mode)::value;
 #pragma unroll 1
-    for (int bt = 0; bt + 1 < full; ++bt) {
-      const int r0 = bt * RB;
+    for (int bt = 0; bt < full; bt += NB) {
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(r0 + RB + r) * row_bytes));
-        xn[r] = NT ? __builtin_nontemporal_load(q) : *q;
-      }
-      sweep_apply<K, RB, MODE>(x, pr, sh_col, np, r0);
+      for (int u = 0; u < NB; ++u) {
+        if (bt + u < full) {  // uniform
+          const int r0 = (bt + u) * RB;
+          if (bt + u + NB - 1 < full) {  // request batch bt+u+NB-1 into the buffer that was stored last
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
-        if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
-      }
+            for (int r = 0; r < RB; ++r) {
+              const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(r0 + (NB - 1) * RB + r) * row_bytes));
+              xb[(u + NB - 1) % NB][r] = NT ? __builtin_nontemporal_load(q) : *q;
+            }
+          }
+          sweep_apply<K, RB, MODE>(xb[u], pr, sh_col, np, r0);
 #pragma unroll
-      for (int r = 0; r < RB; ++r) x[r] = xn[r];
-    }
-    {  // last full batch: nothing left to prefetch
-      const int r0 = (full - 1) * RB;
-      sweep_apply<K, RB, MODE>(x, pr, sh_col, np, r0);
-#pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
-        if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
+          for (int r = 0; r < RB; ++r) {
+            d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+            if (NT) __builtin_nontemporal_store(xb[u][r], q); else *q = xb[u][r];
+          }
+        }
       }
     }
   };
