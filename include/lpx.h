@@ -299,6 +299,50 @@ typedef struct lpx_solve_options {
 int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, const double* b, const double* c,
               int32_t maximize, const lpx_solve_options* opts, lpx_solve_result* result);
 
+/* ------------------------------------------------------------------------------------------------
+ * Several GPUs of one node behind ONE handle (SURVEY §8e, §8b "a handle owns its device set"): the tableau is cut
+ * into contiguous row blocks — device r holds rows [r*m/G, (r+1)*m/G), the partition pivotConcurrently uses for its
+ * row phase (LPState.java:222-223) — c, v, perm and the loop state are replicated.  One process, one host thread;
+ * peer access (hipDeviceEnablePeerAccess) between all devices of the set.  Per pivot decision every device runs
+ * the same persistent decision kernel on its rows and exchanges, by direct stores into its peers' memory over xGMI,
+ * (1) its 32-byte minimum-ratio candidate {ratio, row, pivot element, b[row]} with every device — the
+ * allreduce(min+loc), lowest global row winning ties — and (2) the normalised pivot row, n doubles, from the device
+ * that owns the leaving row to all others; K decisions, then one K-fold sweep of each device's own rows.  No host
+ * decision, no collective library, no Python.  `devices` may name the same ordinal more than once (the shards then
+ * share that GPU: how the path is rehearsed on a one-GPU machine; their decision kernels wait for each other, so the
+ * runtime must give each its own hardware queue — GPU_MAX_HW_QUEUES >= n_dev in the environment, default 4 — or the
+ * loop ends with LPX_DEVICE_ERROR after a bounded spin).  Results are bit-identical to the one-device handle: every
+ * entry sees the same operations in the same order.
+ * ---------------------------------------------------------------------------------------------- */
+#define LPX_MAX_DEVICES 8
+typedef struct lpx_multi lpx_multi;
+/* new LPState(...) over n_dev devices; arguments as lpx_state_create (HOST arrays, A is m x n with leading
+ * dimension lda).  1 <= n_dev <= LPX_MAX_DEVICES, n_dev <= max(m, 1). */
+int lpx_multi_create(int32_t m, int32_t n, const double* A, int64_t lda, const double* b, const double* c, double v,
+                     const int32_t* perm, const int32_t* devices, int32_t n_dev, lpx_multi** out);
+void lpx_multi_destroy(lpx_multi* s);
+int lpx_multi_set_option(lpx_multi* s, int32_t key, int64_t value);   /* lpx_state_set_option on every shard */
+int lpx_multi_set_pricing(lpx_multi* s, int32_t pricing);
+/* getEntering / getLeaving / pivot and the loop of LPSolver.simplex, as lpx_get_entering ... lpx_simplex_loop */
+int lpx_multi_get_entering(lpx_multi* s, int32_t* entering);
+int lpx_multi_get_leaving(lpx_multi* s, int32_t entering, int32_t* leaving, double* ratio);
+int lpx_multi_pivot(lpx_multi* s, int32_t entering, int32_t leaving);
+int lpx_multi_simplex_loop(lpx_multi* s, int64_t max_pivots, int64_t* pivots_done, int32_t* status,
+                           int32_t* track_slot);
+/* Read-back of the whole tableau (rows gathered from the shards) / position-keyed checksums as lpx_state_checksum */
+int lpx_multi_read(lpx_multi* s, double* A, int64_t lda, double* b, double* c, double* v, int32_t* perm);
+int lpx_multi_checksum(lpx_multi* s, uint64_t out[3]);
+/* Sweep timing of shard `shard` as lpx_profile_enable / lpx_profile_read; what shard 0 did as lpx_state_get_info */
+int lpx_multi_profile_enable(lpx_multi* s, int enable);
+int lpx_multi_profile_read(lpx_multi* s, int32_t shard, int64_t* launches, double* total_ms);
+int lpx_multi_get_info(lpx_multi* s, lpx_state_info* out);
+/* BigDecimal LPSolver.solve(LPStandardForm stForm) over n_dev devices: lpx_solve with the row blocks of the tableau
+ * on several GPUs, phase 1 (auxiliary LP, forced first pivot, x0 tracking, degenerate pivot, column drop and
+ * objective restore — LPSolver.java:116-246) included.  opts->device is ignored; keep_state is not supported. */
+int lpx_solve_multi(int32_t m, int32_t n, const double* A, int64_t lda, const double* b, const double* c,
+                    int32_t maximize, const lpx_solve_options* opts, const int32_t* devices, int32_t n_dev,
+                    lpx_solve_result* result);
+
 /* LPState restoreInitialLP(auxLP, initial, indexOfX0)                   LPSolver.java:200-246
  * In place on the auxiliary-LP handle (m x (n+1), as left by phase 1): drops x0's column, rebuilds c and v by
  * substitution in keySet() order (`order`, order_len <= n original-variable indices; NULL = default-name order of all n), renumbers

@@ -6,8 +6,9 @@ LPSolver.solve, LPInputReader.  There is no CPU fallback: without the HIP librar
 """
 from .errors import LPException, SolutionException  # noqa: F401
 from .lp_input_reader import LPInputReader  # noqa: F401
+from .lp_multi import LPMulti  # noqa: F401
 from .lp_solver import LPSolver  # noqa: F401
 from .lp_standard_form import LPStandardForm  # noqa: F401
 from .lp_state import LPState  # noqa: F401
 
-__all__ = ["LPException", "SolutionException", "LPInputReader", "LPSolver", "LPStandardForm", "LPState"]
+__all__ = ["LPException", "SolutionException", "LPInputReader", "LPMulti", "LPSolver", "LPStandardForm", "LPState"]

@@ -103,6 +103,22 @@ SYMBOLS = [
     ("lpx_shard_block_decide", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("lpx_shard_block_sweep", C.c_int, [C.c_void_p, C.c_int32]),
     ("lpx_shard_poll", C.c_int, [C.c_void_p, i64p, ip]),
+    ("lpx_multi_create", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_double, ip, ip, C.c_int32,
+                                   C.POINTER(C.c_void_p)]),
+    ("lpx_multi_destroy", None, [C.c_void_p]),
+    ("lpx_multi_set_option", C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
+    ("lpx_multi_set_pricing", C.c_int, [C.c_void_p, C.c_int32]),
+    ("lpx_multi_get_entering", C.c_int, [C.c_void_p, ip]),
+    ("lpx_multi_get_leaving", C.c_int, [C.c_void_p, C.c_int32, ip, dp]),
+    ("lpx_multi_pivot", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    ("lpx_multi_simplex_loop", C.c_int, [C.c_void_p, C.c_int64, i64p, ip, ip]),
+    ("lpx_multi_read", C.c_int, [C.c_void_p, dp, C.c_int64, dp, dp, dp, ip]),
+    ("lpx_multi_checksum", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("lpx_multi_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("lpx_multi_profile_read", C.c_int, [C.c_void_p, C.c_int32, i64p, dp]),
+    ("lpx_multi_get_info", C.c_int, [C.c_void_p, C.POINTER(StateInfo)]),
+    ("lpx_solve_multi", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(SolveOptions),
+                                  ip, C.c_int32, C.POINTER(SolveResult)]),
     ("lpx_solve", C.c_int, [C.c_int32, C.c_int32, dp, C.c_int64, dp, dp, C.c_int32, C.POINTER(SolveOptions),
                             C.POINTER(SolveResult)]),
     ("lpx_restore_initial_lp", C.c_int, [C.c_void_p, dp, C.c_int32, C.c_int32, ip, C.c_int32]),

@@ -15,6 +15,7 @@
 
 #include "../../include/lpx.h"
 #include "lpx_kernels.h"
+#include "lpx_internal.h"
 
 using lpxk::Buffers;
 using lpxk::Geometry;
@@ -22,19 +23,12 @@ using lpxk::LpxCtl;
 using lpxk::RatioRow;
 
 // ------------------------------------------------------------------------------------------------ errors
-static thread_local std::string g_last_error;
+thread_local std::string g_last_error;
 
-static int fail(int status, const std::string& msg) {
+int fail(int status, const std::string& msg) {
   g_last_error = msg;
   return status;
 }
-
-#define HIP_TRY(expr)                                                                         \
-  do {                                                                                        \
-    hipError_t _e = (expr);                                                                   \
-    if (_e != hipSuccess)                                                                     \
-      return fail(LPX_DEVICE_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e));       \
-  } while (0)
 
 extern "C" const char* lpx_status_message(int status) {
   switch (status) {
@@ -58,57 +52,6 @@ extern "C" int lpx_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return -1;
   return n;
 }
-
-// ------------------------------------------------------------------------------------------------ state
-struct lpx_state {
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  int32_t m = 0;         // local rows
-  int32_t n = 0;         // nonbasic slots (columns in use)
-  int32_t row0 = 0, m_global = 0;
-  int32_t n_cap = 0;     // n the buffers were sized for (phase 1 allocates n+1 and later shrinks n)
-  Buffers B{};
-  Geometry g{};
-  bool nontemporal = false;
-  int pricing = 0;                  // 0 = reference rule (first positive), 1 = Dantzig (opt-in extension)
-  int64_t opt[LPX_OPT_COUNT] = {};  // lpx_option values (include/lpx.h); initial values: env_defaults()
-  lpx_state_info info{};            // what the last loop actually did (lpx_state_get_info)
-  int chain_nb_last = 0;            // decisions of the last k_block_chain launch (chain trace)
-  lpxk::BlockRing R{};
-  int chain_seq = 0;                // k_block_chain launches so far (its two barrier counters alternate)
-  // overlapped blocked loop: decisions of block k+1 (one reserved XCD) beside the sweep of block k (the other 7)
-  hipStream_t ov_chain = nullptr, ov_sweep = nullptr;
-  bool ov_masked = false;           // the pair was created with CU masks (else: plain streams, chain at high priority)
-  int ov_chain_cus = 0;             // CUs the chain stream may use
-  hipEvent_t ev_ov_chain[2] = {nullptr, nullptr}, ev_ov_sweep[2] = {nullptr, nullptr}, ev_ov_join[3] = {nullptr, nullptr, nullptr};
-  double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
-  LpxCtl* h_ctl = nullptr;          // pinned mirror
-  LpxCtl* h_snap = nullptr;         // 2 pinned snapshots for the batched loop (batch k+1 in flight while k is read)
-  hipEvent_t ev_batch[2] = {nullptr, nullptr};
-  // look-ahead pipeline of the sharded loop: parameter ring, second pivot-row buffer, second stream
-  LpxCtl* ring = nullptr;           // 2 device blocks
-  double* prow2 = nullptr;
-  hipStream_t comm_stream = nullptr;
-  hipEvent_t ev_peek = nullptr, ev_decide = nullptr, ev_upd = nullptr;
-  // pipeline = 2: fully overlapped form — out-of-place row update between two tableau buffers so that the peek
-  // of pivot t+1 (comm stream) reads the un-updated tableau while update(t) streams (main stream)
-  int pipeline = 1;
-  double* A2 = nullptr;             // spare tableau / b of the out-of-place update (B.A/A2 and B.b/b2 swap roles)
-  double* A_base[2] = {nullptr, nullptr};   // the two hipMalloc'ed tableau allocations, for hipFree
-  double* b_base[2] = {nullptr, nullptr};
-  double* b2 = nullptr;
-  bool upd_recorded = false;
-  bool settled = true;              // B.A/B.b point at the buffer that holds the current tableau
-  unsigned long long* d_sum = nullptr;
-  // row-update profiling (HIP events on `stream`)
-  int prof = 0;                     // 0 = off, N = bracket every N-th row-update launch with events
-  int64_t prof_seq = 0;
-  std::vector<hipEvent_t> ev;       // pairs
-  size_t ev_used = 0;
-  int64_t prof_launches = 0;
-  double prof_ms = 0.0;
-};
 
 static int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
 
@@ -179,18 +122,18 @@ static void apply_layout_options(lpx_state* s) {
   s->info.nontemporal = s->nontemporal ? 1 : 0;
 }
 
-static int sync_ctl_to_host(lpx_state* s) {
+int sync_ctl_to_host(lpx_state* s) {
   HIP_TRY(hipMemcpyAsync(s->h_ctl, s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
   return 0;
 }
 
-static int push_ctl(lpx_state* s) {
+int push_ctl(lpx_state* s) {
   HIP_TRY(hipMemcpyAsync(s->B.ctl, s->h_ctl, sizeof(LpxCtl), hipMemcpyHostToDevice, s->stream));
   return 0;
 }
 
-static void free_state(lpx_state* s) {
+void free_state(lpx_state* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -223,6 +166,8 @@ static void free_state(lpx_state* s) {
   (void)hipFree(s->R.chain_own_b);
   (void)hipFree(s->R.chain_dbg);
   (void)hipFree(s->R.census);
+  (void)hipFree(s->R.mg_mail);
+  (void)hipFree(s->R.mg_arrive);
   (void)hipFree(s->d_cand);
   if (s->ev_upd) (void)hipEventDestroy(s->ev_upd);
 
@@ -241,7 +186,7 @@ static void free_state(lpx_state* s) {
 }
 
 // Allocates buffers for an m_local x n_cap tableau (n columns in use) and zero-fills the padding.
-static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t m_global, int device,
+int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t m_global, int device,
                        lpx_state** out) {
   if (m_local < 0 || n < 0 || n_cap < n || row0 < 0 || m_global < m_local || row0 + m_local > m_global)
     return fail(LPX_BAD_ARGUMENT, "lpx_state_create: bad dimensions");
@@ -302,7 +247,7 @@ static int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, 
   return 0;
 }
 
-static void init_ctl(lpx_state* s, double v) {
+void init_ctl(lpx_state* s, double v) {
   LpxCtl& c = *s->h_ctl;
   memset(&c, 0, sizeof c);
   c.v = v;
@@ -314,7 +259,7 @@ static void init_ctl(lpx_state* s, double v) {
   c.ticket = 0;
 }
 
-static int upload_common(lpx_state* s, const double* A, int64_t lda, const double* b, const double* c, double v,
+int upload_common(lpx_state* s, const double* A, int64_t lda, const double* b, const double* c, double v,
                          const int32_t* perm, hipMemcpyKind kind) {
   const int32_t m = s->m, n = s->n;
   if (m > 0 && n > 0) {
@@ -382,8 +327,8 @@ extern "C" int lpx_state_dims(const lpx_state* s, int32_t* m_local, int32_t* n, 
 }
 
 // ------------------------------------------------------------------------------------------------ launches
-static int launch_update_profiled(lpx_state* s, const double* prow = nullptr, const LpxCtl* up = nullptr,
-                                  const Buffers* Bin = nullptr, double* A_out = nullptr, double* b_out = nullptr) {
+int launch_update_profiled(lpx_state* s, const double* prow, const LpxCtl* up,
+                                  const Buffers* Bin, double* A_out, double* b_out) {
   if (!prow) prow = s->B.prow;
   if (!up) up = s->B.ctl;
   const Buffers& BB = Bin ? *Bin : s->B;
@@ -442,7 +387,7 @@ extern "C" int lpx_profile_read(lpx_state* s, int64_t* launches, double* total_m
 }
 
 // entering scan at the start of a loop / for getEntering(), honouring the handle's pricing rule
-static void launch_seed_entering(lpx_state* s) {
+void launch_seed_entering(lpx_state* s) {
   if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, true, s->stream);
   else lpxk::launch_entering(s->B, s->n, s->stream);
 }
@@ -461,7 +406,7 @@ static int require_single(lpx_state* s, const char* who) {
   return 0;
 }
 
-static int set_running(lpx_state* s, int64_t max_pivots, int32_t track) {
+int set_running(lpx_state* s, int64_t max_pivots, int32_t track) {
   if (int rc = sync_ctl_to_host(s)) return rc;
   s->h_ctl->status = lpxk::kRunning;
   s->h_ctl->do_update = 0;
@@ -515,12 +460,26 @@ extern "C" int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving) {
 }
 
 // ------------------------------------------------------------------------------------------------ blocked loop
-static int ensure_block_ring(lpx_state* s) {
+hipError_t peer_visible_malloc(const lpx_state* s, void** ptr, size_t bytes) {
+  if (s->peer_written) {
+    if (hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();  // no fine-grained device memory on this runtime: ordinary memory, system-scope accesses
+  }
+  return hipMalloc(ptr, bytes);
+}
+
+int32_t state_n(const lpx_state* s) { return s->n; }
+
+int ensure_block_ring(lpx_state* s) {
   if (s->R.prow) return 0;
   const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
   s->R.mp = mp;
   const size_t K = 2 * lpxk::kBlockMax;  // two halves: the block being decided and the one being swept
-  HIP_TRY(hipMalloc((void**)&s->R.prow, K * (size_t)s->B.ld * sizeof(double)));
+  HIP_TRY(peer_visible_malloc(s, (void**)&s->R.prow, K * (size_t)s->B.ld * sizeof(double)));
+  HIP_TRY(peer_visible_malloc(s, &s->R.mg_mail, 2 * lpxk::kMaxDevices * 32));
+  HIP_TRY(peer_visible_malloc(s, (void**)&s->R.mg_arrive, lpxk::kChainMaxWgs * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(s->R.mg_mail, 0, 2 * lpxk::kMaxDevices * 32, s->stream));
+  HIP_TRY(hipMemsetAsync(s->R.mg_arrive, 0, lpxk::kChainMaxWgs * sizeof(unsigned long long), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.col, K * (size_t)mp * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.col0, K * (size_t)mp * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.row0, K * (size_t)s->B.ld * sizeof(double)));
@@ -570,7 +529,7 @@ static int ensure_spare_tableau(lpx_state* s) {
 // ~18 us + ~0.4 us per pending pivot whatever the size; a sweep moves the tableau once at ~5.6 TB/s up to K = 16
 // and at ~4.7 TB/s at K = 32 (there the 2K fp64 operations per entry co-limit it); the one-pass form costs one
 // pass at ~6.3 TB/s + ~9 us per pivot.  Per pivot: blocked(K) ~ 18 + 0.4 K/2 + sweep(K)/K.
-static int choose_block(const lpx_state* s) {
+int choose_block(const lpx_state* s) {
   int K = (int)s->opt[LPX_OPT_BLOCK];
   if (K == 0) {
     const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
@@ -586,7 +545,7 @@ static int choose_block(const lpx_state* s) {
 // Decisions of the next block: K while the budget lasts, then whatever is left INCLUDING the decision that only
 // reports the end of the budget — one block, one sweep for the tail (the sweep kernels take any number of pending
 // pivots up to their template size at full speed, see sweep_apply).
-static int block_len(int K, int64_t max_pivots, int64_t decided) {
+int block_len(int K, int64_t max_pivots, int64_t decided) {
   if (max_pivots < 0) return K;
   const int64_t room = max_pivots + 1 - decided;  // +1: the decision that reports PIVOT_LIMIT
   return (int)std::max<int64_t>(0, std::min<int64_t>(K, room));
@@ -594,7 +553,7 @@ static int block_len(int K, int64_t max_pivots, int64_t decided) {
 
 // Residency of the persistent decision kernel: every workgroup spins at grid barriers, so the grid must not exceed
 // what the CUs it may use can hold at once.  cus = the CUs of the stream's mask (all of them without a mask).
-static int clamp_chain_wgs(lpx_state* s, int want, int cus) {
+int clamp_chain_wgs(lpx_state* s, int want, int cus) {
   const int per_cu = lpxk::chain_blocks_per_cu();
   const int cap = std::max(1, per_cu * std::max(1, cus));
   s->info.chain_blocks_per_cu = per_cu;
@@ -605,14 +564,14 @@ static int clamp_chain_wgs(lpx_state* s, int want, int cus) {
   return G;
 }
 
-static int device_cus(const lpx_state* s) {
+int device_cus(const lpx_state* s) {
   int ncu = 0;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess) ncu = 0;
   return ncu;
 }
 
 // B / R: destination buffers and the ring half of the block; A_src / b_src != NULL: out of place
-static int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers& B, const lpxk::BlockRing& R,
+int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers& B, const lpxk::BlockRing& R,
                                  const double* A_src, const double* b_src) {
   const bool sample = s->prof > 0 && (s->prof_seq++ % s->prof) == 0;
   if (sample) {
@@ -637,7 +596,7 @@ static int launch_sweep_profiled(lpx_state* s, int K) {
 }
 
 // Ring half h as a ring of its own (what the sweep / fix-up kernels take).
-static lpxk::BlockRing ring_half(const lpx_state* s, int h) {
+lpxk::BlockRing ring_half(const lpx_state* s, int h) {
   lpxk::BlockRing R = s->R;
   const int64_t o = (int64_t)h * lpxk::kBlockMax;
   R.prow += o * s->B.ld;

@@ -98,8 +98,12 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   double* chain_own_b;     // mp: b with all pending pivots applied
   long long* chain_dbg;    // diagnostics (LPX_OPT_CHAIN_TRACE): 5 timestamps per decision of the last block
   unsigned* census;        // [w] = XCC id + 1 of chain workgroup w; [kChainMaxWgs] = OR of (1 << XCC id) of sampled sweep workgroups
+  // shards of an lpx_multi only (else NULL): written by the peers' decision kernels
+  void* mg_mail;                   // MgMail[2][kMaxDevices]
+  unsigned long long* mg_arrive;   // [kChainMaxWgs]
 };
 constexpr int kChainMaxWgs = 256;   // <= one workgroup per CU: the whole grid is resident
+constexpr int kMaxDevices = 8;      // row-block shards of one lpx_multi (the GPUs of one node)
 // decision number `np` of a block (np pivots pending): candidate record like k_propose's
 void launch_block_peek(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int np, double* d_candidate,
                        hipStream_t s);
@@ -110,10 +114,20 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 // not yet reached the tableau (B.A, B.b) this launch reads (n_old pivots; 0: none).  b_from_tableau: first launch
 // of a loop.  seq: launch counter (the two barrier counters alternate).  host_snap: device-visible pointer to a
 // pinned host LpxCtl that receives the loop state when the launch ends.
+// Row-block shards on several devices deciding together (lpx_multi): what a shard's launch needs to know about its
+// peers.  Pointers are peer-mapped device pointers, index = shard rank; [dev] is the shard's own memory.
+struct MgPeers {
+  int n_dev, dev;
+  int row0, m_global;
+  void* mail[kMaxDevices];                 // MgMail[2][kMaxDevices] (32-byte records) of every shard
+  double* prow[kMaxDevices];               // base of every shard's pivot-row ring (BlockRing::prow)
+  unsigned long long* arrive[kMaxDevices]; // arrival words [kChainMaxWgs] of every shard
+};
 // fences: grid-barrier form (bit 0 release fence, bit 1 acquire fence); trace: record phase timestamps in R.chain_dbg.
+// mg != NULL: the launch of one shard of an lpx_multi (m = the shard's rows); every shard must use the same wgs.
 void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
                         int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
-                        hipStream_t s);
+                        hipStream_t s, const MgPeers* mg = nullptr);
 // hipOccupancyMaxActiveBlocksPerMultiprocessor for k_block_chain (256 threads, its static LDS); >= 1
 int chain_blocks_per_cu();
 // apply the valid leading pending pivots (at most K) in one pass

@@ -791,6 +791,34 @@ struct ChainPart {
   int32_t row, pad;
 };
 
+// ---- multi-device decisions -----------------------------------------------------------------------------------
+// Row-block shards on several GPUs of one node, one process (lpx_multi_*): every device runs this same persistent
+// kernel on its shard; the replicated state (c, v, perm, the pivot-row ring) is updated identically everywhere.
+// What crosses devices per decision, by direct stores into peer memory over xGMI (no collective, no host):
+//   (1) the shard's minimum-ratio candidate {ratio, row, a, b_row}: 32 bytes + a sequence tag into a mailbox slot on
+//       every device — allreduce(min+loc) as an all-to-all of 40-byte records, the lowest global row winning ties
+//       exactly as the sequential scan of LPState.java:292-303 does;
+//   (2) the normalised pivot row: the shard that owns the leaving row computes it (thread = column) and stores every
+//       value into every device's replica of the ring ((n+1) doubles = 128 KiB at n = 16384, 7 links in parallel),
+//       then each of its workgroups raises its arrival word on every device.
+// Stores to peers and loads of peer-written data are system-scope (sc0 sc1: write-through / cache-bypassing) and a
+// tag or arrival word is stored only after the storing waves have drained (s_waitcnt vmcnt(0)) and met; with
+// fences bit 0 / 1 a system-scope release / acquire fence is added around every exchange (the default across real
+// devices: the fence-free form is the one MI355X_MICROARCH.md measured valid INSIDE one device only).
+struct MgMail {
+  double ratio, a, bi;
+  int32_t row;
+  uint32_t tag;   // sequence number of the decision, stored last
+};
+static_assert(sizeof(MgMail) == 32, "mailbox record is one 32-byte granule");
+
+__device__ __forceinline__ double ld_sys(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(double* p, double x) {
+  __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ double ld_agent(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -841,7 +869,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
 #define LPX_CHAIN_STEP_A(on, cs_r, pe_r, l_r)                                      \
   {                                                                                \
     const double t_ = __dsub_rn(a, __dmul_rn((cs_r), (pe_r)));                     \
-    const double nv_ = (i == (l_r)) ? (pe_r) : t_;                                 \
+    const double nv_ = (ig == (l_r)) ? (pe_r) : t_;                                \
     a = (on) ? nv_ : a;                                                            \
   }
 #define LPX_CHAIN_STEP_B(on, cs_r, prv_r, e_r, dv_r)                               \
@@ -917,14 +945,23 @@ struct ChainArgs {
   LpxCtl* host_snap;
   long long* dbg;
   unsigned* census;     // [workgroup] = XCC id + 1
+  // ---- row-block shards on several devices (k_block_chain_t<true>; see "multi-device decisions" below)
+  int shard_row0;       // first global row of this shard (0 on one device)
+  int m_global;
+  int n_dev, dev;       // shards taking part / this shard's rank
+  MgMail* mail_peer[kMaxDevices];            // every shard's mailbox [2][kMaxDevices] (peer-mapped); [dev] = own
+  double* prow_peer[kMaxDevices];            // every shard's replica of this block's pivot-row ring half
+  unsigned long long* arrive_peer[kMaxDevices];  // every shard's arrival words [kChainMaxWgs]
 };
 
-__global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
+template <bool MG>
+__global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
   constexpr int KB = kMaxBlock;  // LDS layout of the per-pivot parameters: [0, KB) old half, [KB, 2 KB) own half
   __shared__ RatioRow sh_rr[4];
   __shared__ double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB], sh_win[2];
   __shared__ int sh_e[2 * KB], sh_l[2 * KB];
   __shared__ int sh_fail, sh_restart;
+  const int row0 = MG ? P.shard_row0 : 0;   // global index of local row 0 (a shard of an lpx_multi; 0 on one device)
   const double* __restrict__ A = P.A;
   const double* __restrict__ b = P.b;
   const int64_t ld = P.ld, mp = P.mp;
@@ -969,7 +1006,8 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
       const bool valid = old ? r < n_old : r < s;
       bool same = false;
       if (valid) {  // one wave per workgroup fetches prow_u[e] of every pending pivot u
-        sh_pe[tid] = ld_agent((old ? P.prow_o : P.prow) + (int64_t)r * ld + e);
+        const double* pe_src = (old ? P.prow_o : P.prow) + (int64_t)r * ld + e;
+        sh_pe[tid] = MG ? ld_sys(pe_src) : ld_agent(pe_src);  // on a shard: possibly stored by a peer device
         same = sh_e[tid] == e;
       }
       const unsigned long long mask = __ballot(same);
@@ -988,6 +1026,7 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
       const double* src_b = use_b ? &b[i] : &P.own_b[i];
       double a = *src_a;
       const double bi = *src_b;
+      const int ig = row0 + i;   // global row: what the ring's parameter blocks name
       // this thread's own stores, only the chunks with a live step (after a restart most are dead: the rings
       // exceed the L2, every dead chunk is HBM traffic taken from the sweep running beside this launch); all
       // loads are issued before the first use — one round trip
@@ -1016,7 +1055,7 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
       P.own_col[(int64_t)s * mp + i] = a;
       const double rt = ratio_of(a, bi);
       if (rt < best.ratio) {  // i ascends per thread: strict < keeps the lowest row among equal ratios
-        best = RatioRow{rt, i, 0};
+        best = RatioRow{rt, ig, 0};
         best_a = a;
         best_b = bi;
       }
@@ -1051,9 +1090,52 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
       mine_a = ld_agent(&rec->a);
       mine_b = ld_agent(&rec->bi);
     }
-    const RatioRow w = rr_block_min(mine, sh_rr);
+    RatioRow w = rr_block_min(mine, sh_rr);
     if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
     __syncthreads();
+    const unsigned xtag = P.hand_base + (unsigned)s;  // sequence number of this decision (unique over launches)
+    if constexpr (MG) {
+      // allreduce(min+loc) over the shards: this shard's winner goes into slot `dev` of every device's mailbox,
+      // then every workgroup reduces the n_dev records of its own device's mailbox (lowest global row wins ties)
+      if (lead) {
+        const double wa = (w.row != INT_MAX) ? sh_win[0] : 0.0, wb = (w.row != INT_MAX) ? sh_win[1] : 0.0;
+        for (int d = 0; d < P.n_dev; ++d) {
+          MgMail* rec = &P.mail_peer[d][(s & 1) * kMaxDevices + P.dev];
+          st_sys(&rec->ratio, w.ratio);
+          st_sys(&rec->a, wa);
+          st_sys(&rec->bi, wb);
+          __hip_atomic_store(&rec->row, w.row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (P.fences & 1) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int d = 0; d < P.n_dev; ++d)
+          __hip_atomic_store(&P.mail_peer[d][(s & 1) * kMaxDevices + P.dev].tag, xtag, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __syncthreads();  // sh_win is rewritten below
+      RatioRow theirs = rr_none();
+      double theirs_a = 0.0, theirs_b = 0.0;
+      if (tid < P.n_dev) {
+        const MgMail* rec = &P.mail_peer[P.dev][(s & 1) * kMaxDevices + tid];
+        unsigned spins = 0;
+        while (__hip_atomic_load(&rec->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xtag) {
+          LPX_BARRIER_SLEEP;
+          if (++spins > (1u << 22)) { sh_fail = 1; break; }
+        }
+        if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        theirs.ratio = ld_sys(&rec->ratio);
+        theirs.row = __hip_atomic_load(&rec->row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        theirs_a = ld_sys(&rec->a);
+        theirs_b = ld_sys(&rec->bi);
+      }
+      w = rr_block_min(theirs, sh_rr);
+      if (sh_fail) { if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); } return; }
+      if (w.row != INT_MAX && tid < P.n_dev && theirs.row == w.row) { sh_win[0] = theirs_a; sh_win[1] = theirs_b; }
+      __syncthreads();
+    }
     if (w.row == INT_MAX || !(w.ratio < kInf)) {  // getLeaving() == -1: unbounded
       if (lead) {
         ctl->status = 1; ctl->do_update = 0; ctl->l = -1; ctl->ratio = w.ratio; P.up[s].do_update = 0;
@@ -1076,13 +1158,16 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
     }
     // Row l of the current tableau likewise; a pending pivot u* with the same leaving row REPLACED the row by its
     // normalised row: restart there (own_prow[u*]).  Column e_u of the row becomes -(col_u[l]/p_u) at pivot u.
+    // On shards only the device that holds row l computes it; the others receive the normalised row (see below).
+    const bool owner = !MG || (l >= row0 && l < row0 + m);
+    const int ll = l - row0;  // local index of the leaving row on its owner
     if (tid < 64) {
       const int r = tid & (KB - 1);
       const bool old = tid < KB;
-      const bool valid = old ? r < n_old : r < s;
+      const bool valid = owner && (old ? r < n_old : r < s);
       bool same = false;
       if (valid) {
-        const double csv = ld_agent((old ? P.col_o : P.col) + (int64_t)r * mp + l);
+        const double csv = ld_agent((old ? P.col_o : P.col) + (int64_t)r * mp + ll);
         sh_cs[tid] = csv;
         sh_dv[tid] = -__ddiv_rn(csv, sh_p[tid]);
         same = sh_l[tid] == l;
@@ -1098,7 +1183,24 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
     const double inv_p = __ddiv_rn(1.0, p);                                        // :139
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
     const bool window = !P.dantzig && ld >= 256;  // every thread of workgroup 0 then owns one of the slots 0..255
-    const double* rowl = A + (int64_t)l * ld;
+    const double* rowl = A + (int64_t)(owner ? ll : 0) * ld;
+    if constexpr (MG) {
+      if (!owner) {
+        // wait until every workgroup of the owner has stored its columns of the normalised row into THIS device's
+        // replica of the ring (one arrival word per owner workgroup, raised after its stores have drained)
+        if (tid < G) {
+          const unsigned long long* aw = &P.arrive_peer[P.dev][tid];
+          unsigned spins = 0;
+          while (__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)xtag) {
+            LPX_BARRIER_SLEEP;
+            if (++spins > (1u << 22)) { sh_fail = 1; break; }
+          }
+          if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        }
+        __syncthreads();
+        if (sh_fail) { if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); } return; }
+      }
+    }
     // Column ownership: with the hand-off, workgroup 0 owns slots 0..255 and nothing else (it is on everybody's
     // critical path), the other workgroups share the rest; fixed for the launch, as the private copies require.
     const bool solo0 = window && G > 1;
@@ -1106,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
     for (int j = gid; j < (int)ld; j += (solo0 && blockIdx.x == 0) ? (int)ld : jstep) {
       double x = 0.0;
       const double cj = ld_agent(&P.c[j]);  // this thread's own store (or the initial value)
-      if (j < n) {
+      if (j < n && owner) {
         const double* src_x = rb < 0 ? &rowl[j]
                                      : (rb < KB ? &P.own_prow_o[(int64_t)rb * ld + j] : &P.own_prow[(int64_t)(rb - KB) * ld + j]);
         x = *src_x;
@@ -1134,8 +1236,14 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
         pr = inv_p;
         cn = -__ddiv_rn(pc, p);                                                    // :172
       } else {
-        pr = __ddiv_rn(x, p);                                                      // :144
+        pr = owner ? __ddiv_rn(x, p) : ld_sys(&P.prow[(int64_t)s * ld + j]);       // :144 (the owner's value)
         cn = __dsub_rn(cj, __dmul_rn(pc, pr));                                     // :177
+      }
+      if constexpr (MG) {
+        if (owner) {  // broadcast: the value goes into every other device's replica of the ring
+          for (int d = 0; d < P.n_dev; ++d)
+            if (d != P.dev) st_sys(&P.prow_peer[d][(int64_t)s * ld + j], pr);
+        }
       }
       st_agent(&P.prow[(int64_t)s * ld + j], pr);
       P.own_prow[(int64_t)s * ld + j] = pr;
@@ -1159,14 +1267,30 @@ __global__ __launch_bounds__(256) void k_block_chain(const ChainArgs P) {
         }
       }
     }
+    if constexpr (MG) {
+      if (owner && P.n_dev > 1) {  // this workgroup's columns are on their way to every peer: drain, meet, signal
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          if (P.fences & 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          for (int d = 0; d < P.n_dev; ++d)
+            if (d != P.dev)
+              __hip_atomic_store(&P.arrive_peer[d][blockIdx.x], (unsigned long long)xtag, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
     // the row owners add pivot s to their two running columns: the entering column after the pivot (what a later
     // decision restarts from) and b — after the columns, so that workgroup 0 publishes the entering slot first
     for (int i = gid; i < m; i += T) {
       const double colv = P.own_col[(int64_t)s * mp + i];
       const double* src_b = use_b ? &b[i] : &P.own_b[i];
       const double bcur = *src_b;
-      P.own_dvc[(int64_t)s * mp + i] = (i == l) ? inv_p : -__ddiv_rn(colv, p);    // :157 / :139
-      P.own_b[i] = (i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));          // :146 / :164
+      P.own_dvc[(int64_t)s * mp + i] = (row0 + i == l) ? inv_p : -__ddiv_rn(colv, p);    // :157 / :139
+      P.own_b[i] = (row0 + i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));          // :146 / :164
     }
     {
       const RatioRow w2 = rr_block_min(cand, sh_rr);
@@ -1739,7 +1863,7 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 // alternate); B.A / B.b: the tableau version to read.
 void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
                         int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
-                        hipStream_t s) {
+                        hipStream_t s, const MgPeers* mg) {
   // fences = 2 (the engine's default), acquire only: everything that crosses workgroups inside the launch is stored
   // write-through (st_agent = sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets, ONE lane
   // arrives with an agent-scope atomic add, the poller's loads of the handed-off bytes are all sc1 loads (ld_agent)
@@ -1767,12 +1891,23 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   P.hand_base = (unsigned)(seq + 1) * 64u;  // > any sequence of earlier launches (<= kBlockMax decisions each)
   P.dantzig = dantzig; P.fences = fences; P.host_snap = host_snap; P.dbg = trace ? R.chain_dbg : nullptr;
   P.census = R.census;
-  hipLaunchKernelGGL(k_block_chain, dim3(G), dim3(256), 0, s, P);
+  if (mg) {
+    P.shard_row0 = mg->row0; P.m_global = mg->m_global; P.n_dev = mg->n_dev; P.dev = mg->dev;
+    for (int d = 0; d < mg->n_dev && d < kMaxDevices; ++d) {
+      P.mail_peer[d] = reinterpret_cast<MgMail*>(mg->mail[d]);
+      P.prow_peer[d] = mg->prow[d] + ho * B.ld;   // the same ring half on every shard
+      P.arrive_peer[d] = mg->arrive[d];
+    }
+    hipLaunchKernelGGL(k_block_chain_t<true>, dim3(G), dim3(256), 0, s, P);
+  } else {
+    P.m_global = m; P.n_dev = 1;
+    hipLaunchKernelGGL(k_block_chain_t<false>, dim3(G), dim3(256), 0, s, P);
+  }
 }
 
 int chain_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_block_chain, 256, 0) != hipSuccess) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_block_chain_t<true>, 256, 0) != hipSuccess) {
     (void)hipGetLastError();
     nb = 1;
   }

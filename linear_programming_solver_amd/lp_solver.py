@@ -31,10 +31,12 @@ class SolveInfo:
 
 
 class LPSolver:
-    def __init__(self, device=0, max_pivots=-1, pricing="reference"):
+    def __init__(self, device=0, max_pivots=-1, pricing="reference", devices=None):
         """pricing="reference": the reference's first-positive rule (default, parity with the Java solver);
-        pricing="dantzig": opt-in largest-coefficient rule (same optimum, ~10x fewer pivots, no pivot parity)."""
+        pricing="dantzig": opt-in largest-coefficient rule (same optimum, ~10x fewer pivots, no pivot parity).
+        devices=[d0, d1, ...]: solve with the row blocks of the tableau on several GPUs (lpx_solve_multi)."""
         self.device = int(device)
+        self.devices = None if devices is None else [int(d) for d in devices]
         self.max_pivots = int(max_pivots)
         self.pricing = _lib.PRICING[pricing]
         self.last = None
@@ -65,9 +67,16 @@ class LPSolver:
         opts.perm_out = perm.ctypes.data_as(_lib.ip)
         opts.x_out = x.ctypes.data_as(_lib.dp)
         res = _lib.SolveResult()
-        rc = L.lpx_solve(m, n, A.ctypes.data_as(_lib.dp) if A.size else None, max(n, 1),
-                         b.ctypes.data_as(_lib.dp) if m else None, c.ctypes.data_as(_lib.dp) if n else None,
-                         1 if st_form.maximize else 0, C.byref(opts), C.byref(res))
+        if self.devices is None:
+            rc = L.lpx_solve(m, n, A.ctypes.data_as(_lib.dp) if A.size else None, max(n, 1),
+                             b.ctypes.data_as(_lib.dp) if m else None, c.ctypes.data_as(_lib.dp) if n else None,
+                             1 if st_form.maximize else 0, C.byref(opts), C.byref(res))
+        else:
+            dev = np.array(self.devices, dtype=np.int32)
+            rc = L.lpx_solve_multi(m, n, A.ctypes.data_as(_lib.dp) if A.size else None, max(n, 1),
+                                   b.ctypes.data_as(_lib.dp) if m else None, c.ctypes.data_as(_lib.dp) if n else None,
+                                   1 if st_form.maximize else 0, C.byref(opts), dev.ctypes.data_as(_lib.ip), len(dev),
+                                   C.byref(res))
         self.last = SolveInfo(res, perm[: n + m].copy(), x[:n].copy())
         if rc != _lib.OPTIMAL:
             raise_for_status(rc)

@@ -9,6 +9,12 @@ import sys
 
 import pytest
 
+# The multi-device path is rehearsed on ONE GPU (every shard on device 0): its persistent decision kernels wait for each
+# other, so each needs a hardware queue of its own.  The HIP runtime maps streams onto 4 hardware queues by default;
+# this must be set before the runtime initialises (i.e. before torch / liblpx touch the GPU).  On a real multi-GPU
+# node every device has its own queues and nothing needs to be set.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,223 @@
+"""`-m gpu` parity tests of the multi-device path (lpx_multi_*, lpx_solve_multi): row-block shards behind ONE C-ABI
+handle, the persistent decision kernels exchanging candidates and pivot rows by direct stores into each other's
+memory.  The test box has one GPU, so every "device" of the set is device 0 (peer-to-self): the shards, their
+mailboxes and ring replicas are distinct allocations and the kernels really run side by side and wait for each
+other — only the xGMI hop is missing.  Checker: the fp64 oracle, bit for bit."""
+import ctypes as C
+import json
+import os
+from decimal import Decimal
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lps():
+    import linear_programming_solver_amd as pkg
+    from linear_programming_solver_amd import _lib
+    if _lib.lib().lpx_device_count() < 1:
+        pytest.fail("no MI355X visible: the product path has no CPU fallback")
+    return pkg
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_state_bits_equal(got, want, what=""):
+    gA, gb, gc, gv, gperm = got
+    wA, wb, wc, wv, wperm = want
+    assert np.array_equal(bits(gA), bits(wA)), "A differs " + what
+    assert np.array_equal(bits(gb), bits(wb)), "b differs " + what
+    assert np.array_equal(bits(gc), bits(wc)), "c differs " + what
+    assert bits(np.array([gv]))[0] == bits(np.array([wv]))[0], "v differs " + what
+    assert list(gperm) == list(wperm), "perm differs " + what
+
+
+def dense_lp(m, n, seed):
+    rng = np.random.default_rng(seed)
+    return rng.random((m, n)), (n / 4.0) * (1.0 + rng.random(m)), rng.random(n)
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape,block", [((64, 100), 4), ((257, 513), 16), ((1000, 260), 32), ((9, 2100), 8)])
+def test_multi_loop_matches_oracle(lps, oracle, ndev, shape, block):
+    """Budgets that are not multiples of the block, resumed loops, a run to optimality — every intermediate state of
+    the sharded tableau (rows gathered from the shards) equals the oracle's."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=11 * m + n)
+    mt = lps.LPMulti(A, b, c, devices=[0] * ndev, block=block)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (1, block, 2 * block + 3, 0, 5 * block - 1, -1):
+        status, pivots, _ = mt.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget)
+        assert (status, pivots) == (want["status"], want["pivots"]), (ndev, shape, block, budget)
+        assert_state_bits_equal(mt.read(), ref.read(), "ndev %d block %d budget %d of %s" % (ndev, block, budget, shape))
+    mt.close()
+
+
+@pytest.mark.parametrize("fences", [2, 3])
+def test_multi_wide_decision_kernels_side_by_side(lps, oracle, fences):
+    """Four shards of a 4096 x 8192 tableau on one GPU: four persistent decision kernels of 16+ workgroups each run
+    beside each other, spin on each other's mailboxes and arrival words, the owner of the leaving row changes from
+    decision to decision.  Both exchange forms (fence-free, release + acquire)."""
+    m, n = 4096, 8192
+    A, b, c = dense_lp(m, n, seed=4)
+    mt = lps.LPMulti(A, b, c, devices=[0, 0, 0, 0], block=32, options={"chain_fences": fences})
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (100, 33):
+        status, pivots, _ = mt.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget, threads=16)
+        assert (status, pivots) == (want["status"], want["pivots"]) == (9, budget)
+        assert_state_bits_equal(mt.read(), ref.read(), "fences %d budget %d" % (fences, budget))
+    info = mt.info()
+    assert 4 * info["chain_wgs"] <= 4 * info["chain_resident_max"] and info["chain_wgs"] >= 8, info
+    mt.close()
+
+
+def test_multi_step_api_and_ties(lps, oracle):
+    """getEntering / getLeaving / pivot over shards; ratio ties across shard borders go to the lowest global row."""
+    m, n = 70, 40
+    A = np.ones((m, n)); b = np.full(m, 3.0); c = np.arange(n, 0, -1).astype(float)
+    mt = lps.LPMulti(A, b, c, devices=[0, 0, 0])
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for _ in range(6):
+        e, e_ref = mt.get_entering(), ref.get_entering()
+        assert e == e_ref
+        if e < 0:
+            break
+        l, l_ref = mt.get_leaving(e), ref.get_leaving(e)
+        assert l == l_ref
+        mt.pivot(e, l)
+        ref.pivot(e, l)
+        assert_state_bits_equal(mt.read(), ref.read())
+    status, pivots, _ = mt.simplex_loop()
+    want = ref.simplex_loop()
+    assert (status, pivots) == (want["status"], want["pivots"])
+    assert_state_bits_equal(mt.read(), ref.read())
+    mt.close()
+    # unbounded in the middle of a block, the unbounded column's rows spread over two shards
+    mt = lps.LPMulti([[1.0, 0.0], [0.5, 0.0]], [1.0, 1.0], [1.0, 1.0], devices=[0, 0], block=8)
+    assert mt.simplex_loop()[:2] == (1, 1)
+    mt.close()
+    with pytest.raises(ZeroDivisionError):
+        mt = lps.LPMulti([[0.0, 1.0], [1.0, 1.0]], [1.0, 2.0], [1.0, 1.0], devices=[0, 0])
+        mt.pivot(0, 0)
+
+
+def test_multi_dantzig_and_tracking(lps, oracle):
+    A, b, c = dense_lp(300, 700, seed=99)
+    mt = lps.LPMulti(A, b, c, devices=[0, 0], pricing="dantzig", block=8)
+    ref = oracle.State(A, b, c, kind=oracle.FP64, pricing=1)
+    status, pivots, _ = mt.simplex_loop()
+    want = ref.simplex_loop()
+    assert (status, pivots) == (want["status"], want["pivots"])
+    assert_state_bits_equal(mt.read(), ref.read())
+    mt.close()
+    # x0 tracking through a sharded phase-1 loop (LPSolverSpec.groovy:113-124 / logs/lp_solver.log:196)
+    A = [[1, 0, -1], [-1, 0, -1], [0, 1, -1], [0, -1, -1]]
+    aux = lps.LPMulti(A, [10, -2, 10, -2], [0, 0, -1], devices=[0, 0], block=2)
+    aux.pivot(2, 1)
+    status, _, x0 = aux.simplex_loop(track_slot=1 + 3)
+    assert status == 0 and aux.v == 0 and x0 == 1
+    aux.close()
+
+
+def test_solve_multi_reference_vectors(lps, reference_vectors):      # LPSolverSpec.groovy:76-111, :151-192
+    STATUS = {"OPTIMAL": 0, "UNBOUNDED": 1, "INFEASIBLE": 2}
+    for case in reference_vectors["solve"]:
+        m = len(case["b"])
+        for ndev in (1, 2, 3):
+            if ndev > m:
+                continue
+            form = lps.LPStandardForm(case["A"], case["b"], case["c"], maximize=case["maximize"])
+            solver = lps.LPSolver(devices=[0] * ndev)
+            if case["status"] == "OPTIMAL":
+                ans = solver.solve(form, restore_order=case.get("restore_order"))
+                assert ans == Decimal(case["answer"]), (case["source"], ndev, ans)
+            else:
+                exc = lps.SolutionException if case["status"] == "UNBOUNDED" else lps.LPException
+                with pytest.raises(exc) as ei:
+                    solver.solve(form)
+                assert str(ei.value) == case["message"], case["source"]
+                assert solver.last.status == STATUS[case["status"]]
+
+
+def test_solve_multi_golden_cases_match_single_device(lps, oracle, decimal_goldens):
+    """Every golden LP (feasible / infeasible start, degenerate pivot, unbounded, infeasible, the restoreInitialLP
+    index fault) through 2 and 3 shards: status, pivot counts, x0's slot, the objective's bits and the basis equal
+    the fp64 oracle's — i.e. phase 1 on shards is the reference's phase 1."""
+    for case in decimal_goldens["lp_cases"]:
+        m, n = case["m"], case["n"]
+        A = np.array([float(x) for x in case["A"]]).reshape(m, n)
+        b = np.array([float(x) for x in case["b"]])
+        c = np.array([float(x) for x in case["c"]])
+        want, wst = oracle.solve(A, b, c, maximize=case["maximize"], kind=oracle.FP64)
+        for ndev in (2, 3):
+            if ndev > m:
+                continue
+            solver = lps.LPSolver(devices=[0] * ndev)
+            try:
+                solver.solve(lps.LPStandardForm(A, b, c, maximize=case["maximize"]))
+            except (lps.LPException, IndexError):
+                pass
+            got = solver.last
+            name = "%s on %d shards" % (case["name"], ndev)
+            assert got.status == want["status"], name
+            assert got.phase1_used == want["phase1_used"], name
+            assert (got.pivots_phase1, got.pivots_phase2) == (want["pivots1"], want["pivots2"]), name
+            assert got.x0_slot == want["x0_slot"], name
+            assert bits(np.array([got.objective]))[0] == bits(np.array([want["objective"]]))[0], name
+            if got.status == 0:
+                assert list(got.perm) == list(wst.read()[4]), name
+                assert got.objective_text == want["objective_text"], name
+
+
+def test_cfg5_phase1_through_four_shards_basis_bit_exact(lps):
+    """BASELINE cfg5 (m = n = 4096, integer data, negative right-hand sides, massive ratio ties) through FOUR shards:
+    auxiliary LP, forced first pivot, x0 tracking, column drop and objective restore on shards; the basis, pivot
+    counts, x0's final slot and the 6-decimal objective text equal the committed decimal-15 golden."""
+    from linear_programming_solver_amd import _lib
+    from tests.golden.gen_cfg5 import make_cfg5
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cfg5_golden_4096x4096.json")))
+    m, n = gold["m"], gold["n"]
+    A, b, c = make_cfg5(m, n, gold["seed"])
+    L = _lib.lib()
+    opts = _lib.SolveOptions()
+    opts.max_pivots = -1
+    perm = np.zeros(n + m, dtype=np.int32)
+    opts.perm_out = perm.ctypes.data_as(_lib.ip)
+    res = _lib.SolveResult()
+    dev = np.zeros(4, dtype=np.int32)
+    rc = L.lpx_solve_multi(m, n, A.ctypes.data_as(_lib.dp), n, b.ctypes.data_as(_lib.dp), c.ctypes.data_as(_lib.dp), 1,
+                           C.byref(opts), dev.ctypes.data_as(_lib.ip), 4, C.byref(res))
+    assert rc == 0 and res.status == gold["status"] == 0
+    assert res.phase1_used == 1
+    assert (res.pivots_phase1, res.pivots_phase2) == (gold["pivots_phase1"], gold["pivots_phase2"])
+    assert res.x0_slot == gold["x0_slot"]
+    assert res.objective_text.decode() == gold["objective_text"]
+    first_diff = next((i for i in range(n + m) if perm[i] != gold["perm"][i]), None)
+    assert first_diff is None, "basis permutation diverges from the decimal reference at slot %r" % first_diff
+
+
+def test_multi_cfg4_shape_two_blocks_vs_oracle(lps, oracle):
+    """One eighth of cfg4's rows per shard is 4096 x 16384: 8 shards of that shape ARE cfg4.  Two shards of 4096 rows
+    (8192 x 16384 in all) for 70 pivots against the oracle: the per-device work of the 8-GPU job, full width."""
+    import bench
+    from linear_programming_solver_amd.lp_state import checksum_host
+    m, n = 8192, 16384
+    A, b, c = bench.gen_rows(m, n, 1, 0, m)
+    mt = lps.LPMulti(A, b, c, devices=[0, 0])
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    status, pivots, _ = mt.simplex_loop(max_pivots=70)
+    want = ref.simplex_loop(max_pivots=70, threads=16)
+    assert (status, pivots) == (want["status"], want["pivots"]) == (9, 70)
+    wA, wb, wc, wv, wperm = ref.read()
+    _, gb, gc, gv, gperm = mt.read(want_A=False)
+    assert gv == wv and list(gperm) == list(wperm)
+    assert np.array_equal(bits(gb), bits(wb)) and np.array_equal(bits(gc), bits(wc))
+    assert mt.checksum() == checksum_host(wA, wb, wc)
+    mt.close()
