@@ -258,6 +258,14 @@ def main():
                          "several decisions, else 1 (then the look-ahead pipeline is used); 1 = off")
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the row-block shard engine + the torch.distributed collective even at N=1")
+    ap.add_argument("--multi-backend", default=os.environ.get("LPX_BENCH_MULTI", "peer"), choices=["peer", "rccl"],
+                    help="N>1: 'peer' = lpx_multi through the C ABI (ONE process — rank 0 — drives all N GPUs, the "
+                         "persistent decision kernels exchange candidates and pivot rows by direct xGMI stores; the "
+                         "other ranks only join the barriers); 'rccl' = one process per GPU, one RCCL all_gather per "
+                         "decision issued from Python (linear_programming_solver_amd/sharded.py)")
+    ap.add_argument("--rehearse-shards", type=int, default=0,
+                    help="N=1: run the lpx_multi path with this many shards, all on this GPU (peer-to-self rehearsal; "
+                         "needs GPU_MAX_HW_QUEUES >= shards in the environment)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout: RCCL prints a version banner to fd 1 at init, so everything
@@ -281,7 +289,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    sharded = world > 1 or args.force_sharded
+    peer = (world > 1 and args.multi_backend == "peer") or (world == 1 and args.rehearse_shards > 0)
+    sharded = (world > 1 or args.force_sharded) and not peer
+    if peer and world > 1:
+        # one process drives every GPU: the other ranks only take part in the barriers (CPU backend, no GPU work)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -295,16 +310,21 @@ def main():
                                 device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
 
     m, n = WORKLOADS[args.workload]
-    r0, r1 = row_block(m, world, rank)
+    nshards = world if world > 1 else max(1, args.rehearse_shards)
+    if peer:
+        r0, r1 = (0, m) if rank == 0 else (0, 0)     # rank 0 holds the whole problem and cuts it into row blocks
+    else:
+        r0, r1 = row_block(m, world, rank)
     t_gen = time.time()
-    A, b, c = gen_rows(m, n, args.seed, r0, r1)
+    A, b, c = gen_rows(m, n, args.seed, r0, r1) if r1 > r0 else (None, None, None)
     t_gen = time.time() - t_gen
     K, W = args.steps, args.warmup
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not (peer and rank != 0):
+            torch.cuda.synchronize()
 
     options = {}
     for kv in args.option:
@@ -342,7 +362,46 @@ def main():
         return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
                 "pivots_per_launch": pivots_per_launch, "upload_s": t_up, "info": st.info()}
 
-    if not sharded:
+    def run_peer(Aw, bw, cw):
+        """the same protocol on the lpx_multi handle: rank 0 drives all shards, every rank joins the barriers"""
+        from linear_programming_solver_amd import LPMulti
+        mt, t_up, block, launches, avg_ms, ppl, info = None, 0.0, 0, 0, float("nan"), float("nan"), None
+        if rank == 0:
+            devices = list(range(world)) if world > 1 else [local_rank] * nshards
+            t_up = time.perf_counter()
+            mt = LPMulti(Aw, bw, cw, devices=devices, options=options)
+            t_up = time.perf_counter() - t_up
+            status, piv, _ = mt.simplex_loop(max_pivots=W)
+            assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
+            mt.profile_enable(1 if args.event_every > 0 else 0)
+        barrier()
+        t0 = time.perf_counter()
+        if rank == 0:
+            status, piv, _ = mt.simplex_loop(max_pivots=K)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if rank == 0:
+            assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
+            launches, kernel_ms = mt.profile_read(0)
+            mt.profile_enable(0)
+            info = mt.info()
+            block = info["block"]
+            avg_ms = kernel_ms / launches if launches else float("nan")
+            ppl = K / float(launches) if launches else float("nan")
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return {"st": mt, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
+                "pivots_per_launch": ppl, "upload_s": t_up, "info": info}
+
+    if peer:
+        r1_ = run_peer(A, b, c)
+        eng = st = r1_["st"]
+        elapsed, block, launches, avg_ms = r1_["elapsed"], r1_["block"], r1_["launches"], r1_["avg_ms"]
+        pivots_per_launch, t_up, info = r1_["pivots_per_launch"], r1_["upload_s"], r1_["info"]
+        objective = st.v if rank == 0 else None
+    elif not sharded:
         r1_ = run_single(A, b, c, m, n)
         eng = st = r1_["st"]
         elapsed, block, launches, avg_ms = r1_["elapsed"], r1_["block"], r1_["launches"], r1_["avg_ms"]
@@ -389,7 +448,7 @@ def main():
         avg_ms = kernel_ms / launches if launches else float("nan")
 
     if rank == 0:
-        m_local = r1 - r0
+        m_local = (m // nshards) if peer else (r1 - r0)      # rows one sweep launch covers (shard 0)
         line = {
             "metric": "simplex_pivots_per_sec", "value": K / elapsed, "unit": "pivots/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
@@ -398,9 +457,14 @@ def main():
             "config": {"workload": "%s: dense random LP m=%d n=%d fp64 (A~U(0,1), b=(n/4)U(1,2), c~U(0,1), max), "
                                    "first-positive entering rule, %d pivots after %d warm-up" % (args.workload, m, n, K, W),
                        "m": m, "n": n, "seed": args.seed, "pivots_per_sweep": block,
-                       "parallelism": "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot, %s" % (
-                           world, ("blocked x%d" % block) if block > 1 else
-                           ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline))},
+                       "parallelism": (
+                           ("row-block x%d behind one lpx_multi handle (one process, %s): per decision a 32-byte "
+                            "candidate to every peer + the pivot row from its owner by direct stores, blocked x%d" % (
+                                nshards, "%d GPUs, xGMI peer access" % world if world > 1 else
+                                "REHEARSAL: all shards on this one GPU", block)) if peer else
+                           "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot, %s" % (
+                               world, ("blocked x%d" % block) if block > 1 else
+                               ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline)))},
             "roofline": roofline_block(m_local, n, pivots_per_launch, avg_ms,
                                        "k_update" if block == 1 else "k_update_multi", launches,
                                        load_traffic(args.workload, world, block)),
@@ -410,10 +474,10 @@ def main():
         }
         if info is not None:   # what the engine actually did: grid of the decision kernel, its residency bound, CU masks
             line["engine"] = info
-        if world == 1 and not sharded and not args.no_parity:
+        if (peer or (world == 1 and not sharded)) and not args.no_parity:
             # the checker: the same LP replayed on the fp64 oracle for warm-up + steps pivots (outside the timed region)
             line["parity_after_timed_region"] = parity_after(st, A, b, c, W + K, m, n, host_cores(), args.parity_max_pivots)
-        if world == 1 and not sharded and args.workload == "cfg4" and not args.no_cfg3:
+        if world == 1 and not sharded and not peer and args.workload == "cfg4" and not args.no_cfg3:
             # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
             # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)
             st.close()
@@ -431,14 +495,14 @@ def main():
                                                                          host_cores(), args.parity_max_pivots)
             r3["st"].close()
             del A3, b3, c3
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not peer and not args.no_cpu_baseline:
             rows_s = min(m, 8192)
             line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))
             line["cpu_baseline_java"] = java_baseline(m, n, args.cpu_budget_s)
             line["gpu_over_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
             line["gpu_over_cpu_baseline_fp64"] = line["value"] / line["cpu_baseline_fp64"]["value"]
         os.write(json_fd, (json.dumps(line) + "\n").encode())
-    if hasattr(eng, "close"):
+    if eng is not None and hasattr(eng, "close"):
         eng.close()
     if dist is not None:
         dist.barrier()

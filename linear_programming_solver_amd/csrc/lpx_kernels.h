@@ -119,6 +119,7 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 struct MgPeers {
   int n_dev, dev;
   int row0, m_global;
+  int mail_slot0;                          // parity of the decisions taken by earlier launches of the loop
   void* mail[kMaxDevices];                 // MgMail[2][kMaxDevices] (32-byte records) of every shard
   double* prow[kMaxDevices];               // base of every shard's pivot-row ring (BlockRing::prow)
   unsigned long long* arrive[kMaxDevices]; // arrival words [kChainMaxWgs] of every shard

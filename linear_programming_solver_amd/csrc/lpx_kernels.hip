@@ -949,6 +949,7 @@ struct ChainArgs {
   int shard_row0;       // first global row of this shard (0 on one device)
   int m_global;
   int n_dev, dev;       // shards taking part / this shard's rank
+  int mail_slot0;       // parity of the decisions taken by earlier launches of this loop (see the exchange)
   MgMail* mail_peer[kMaxDevices];            // every shard's mailbox [2][kMaxDevices] (peer-mapped); [dev] = own
   double* prow_peer[kMaxDevices];            // every shard's replica of this block's pivot-row ring half
   unsigned long long* arrive_peer[kMaxDevices];  // every shard's arrival words [kChainMaxWgs]
@@ -1095,12 +1096,16 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     __syncthreads();
     const unsigned xtag = P.hand_base + (unsigned)s;  // sequence number of this decision (unique over launches)
     if constexpr (MG) {
+      // The two mailbox slots alternate with the decisions of the whole LOOP, not of the launch: a device may be one
+      // decision ahead of a peer — also across the boundary between two launches (a block of odd length would reuse
+      // the slot its last decision used) — never two.
+      const int mslot = (P.mail_slot0 + s) & 1;
       // allreduce(min+loc) over the shards: this shard's winner goes into slot `dev` of every device's mailbox,
       // then every workgroup reduces the n_dev records of its own device's mailbox (lowest global row wins ties)
       if (lead) {
         const double wa = (w.row != INT_MAX) ? sh_win[0] : 0.0, wb = (w.row != INT_MAX) ? sh_win[1] : 0.0;
         for (int d = 0; d < P.n_dev; ++d) {
-          MgMail* rec = &P.mail_peer[d][(s & 1) * kMaxDevices + P.dev];
+          MgMail* rec = &P.mail_peer[d][mslot * kMaxDevices + P.dev];
           st_sys(&rec->ratio, w.ratio);
           st_sys(&rec->a, wa);
           st_sys(&rec->bi, wb);
@@ -1112,14 +1117,14 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         for (int d = 0; d < P.n_dev; ++d)
-          __hip_atomic_store(&P.mail_peer[d][(s & 1) * kMaxDevices + P.dev].tag, xtag, __ATOMIC_RELAXED,
+          __hip_atomic_store(&P.mail_peer[d][mslot * kMaxDevices + P.dev].tag, xtag, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_SYSTEM);
       }
       __syncthreads();  // sh_win is rewritten below
       RatioRow theirs = rr_none();
       double theirs_a = 0.0, theirs_b = 0.0;
       if (tid < P.n_dev) {
-        const MgMail* rec = &P.mail_peer[P.dev][(s & 1) * kMaxDevices + tid];
+        const MgMail* rec = &P.mail_peer[P.dev][mslot * kMaxDevices + tid];
         unsigned spins = 0;
         while (__hip_atomic_load(&rec->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xtag) {
           LPX_BARRIER_SLEEP;
@@ -1893,6 +1898,7 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   P.census = R.census;
   if (mg) {
     P.shard_row0 = mg->row0; P.m_global = mg->m_global; P.n_dev = mg->n_dev; P.dev = mg->dev;
+    P.mail_slot0 = mg->mail_slot0;
     for (int d = 0; d < mg->n_dev && d < kMaxDevices; ++d) {
       P.mail_peer[d] = reinterpret_cast<MgMail*>(mg->mail[d]);
       P.prow_peer[d] = mg->prow[d] + ho * B.ld;   // the same ring half on every shard

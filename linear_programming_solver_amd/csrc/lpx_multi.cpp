@@ -280,7 +280,8 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
     for (int r = 0; r < G; r++) {
       lpx_state* s = M->sh[r];
       HIP_TRY(hipSetDevice(M->device[r]));
-      const lpxk::MgPeers P = peers_of(M, r);
+      lpxk::MgPeers P = peers_of(M, r);
+      P.mail_slot0 = (int)(decided & 1);   // every earlier block of this loop took all its decisions
       lpxk::launch_block_chain(s->B, s->R, s->n, s->m, nb, 0, 0, 0, 1, M->seq, dantzig, wgs, fences, trace,
                                M->d_snap[r] + slot, s->stream, &P);
       s->chain_nb_last = nb;
