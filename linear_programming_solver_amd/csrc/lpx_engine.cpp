@@ -611,7 +611,10 @@ lpxk::BlockRing ring_half(const lpx_state* s, int h) {
 // XCD i % 8, and an XCD whose bits are ALL clear is not excluded — it runs unmasked.  So a stream cannot be kept off
 // an XCD; what a mask can do is reserve the same few CUs on every XCD.  The decisions get the last kChainCusPerXcd CUs
 // of each XCD (one resident workgroup each), the sweep the others: the two kernels never wait for each other's CUs.
-static constexpr int kChainCusPerXcd = 4;
+#ifndef LPX_CHAIN_CUS_PER_XCD
+#define LPX_CHAIN_CUS_PER_XCD 4
+#endif
+static constexpr int kChainCusPerXcd = LPX_CHAIN_CUS_PER_XCD;
 static int ensure_overlap_streams(lpx_state* s) {
   if (s->ov_chain) return 0;
   hipDeviceProp_t prop;

@@ -1,7 +1,8 @@
 """HBM bytes per launch of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
 MI355X_MICROARCH.md's HBM section prescribes for gfx950 (FETCH_SIZE counts 128-B requests as 64 B: x2; both
 counters are in KiB).  Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv>
-<kernel substring> <m> <n> <label> [min_duration_filter]  -> JSON on stdout (profiles/traffic_<workload>_n1.json).
+<kernel substring> <m> <n> <label> <pivots_per_sweep>  -> JSON on stdout (profiles/traffic_<workload>_n1.json;
+bench.py quotes it as roofline.traffic only when workload, GPU count and pivots per sweep match its own run).
 
 Only FULL launches are averaged: those whose counter value is within 5 % of the largest one (the warm-up and the
 last block of a budgeted run apply fewer pivots or run other template instances)."""
@@ -23,6 +24,7 @@ def per_launch(path, counter, kernel_sub):
 def main():
     fpath, wpath, ksub, m, n, label = sys.argv[1:7]
     m, n = int(m), int(n)
+    block = int(sys.argv[7]) if len(sys.argv) > 7 else 1
     f = per_launch(fpath, "FETCH_SIZE", ksub)
     w = per_launch(wpath, "WRITE_SIZE", ksub)
     one_pass = 16.0 * m * n
@@ -31,6 +33,7 @@ def main():
     rd, wr = 2.0 * fmean * 1024.0, wmean * 1024.0
     out = {
         "workload": label,
+        "pivots_per_sweep": block,
         "kernel": ksub,
         "launches_sampled": [len(f), len(w)],
         "FETCH_SIZE_KiB_mean": fmean,

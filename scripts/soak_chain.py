@@ -30,7 +30,11 @@ def main():
         A = rng.random((m, n))
         b = (n / 4.0) * (1.0 + rng.random(m))
         c = rng.random(n)
-        st = lps.LPState(A, b, c, block=block)
+        # every third LP with the conservative barrier (release + acquire): the self-check of the acquire-only default
+        opts = {"chain_fences": 3} if n_lp % 3 == 2 else {}
+        if n_lp % 4 == 1:
+            opts["chain_wgs"] = 33     # the decision kernel at full width also on these small shapes
+        st = lps.LPState(A, b, c, block=block, options=opts)
         ref = oracle.State(A, b, c, kind=oracle.FP64)
         while True:
             budget = int(rng.choice([-1, 1, block, 3 * block + 1, 257, 1000]))

@@ -26,6 +26,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with gpurun / at round end)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """Some GPU tests hand torch CUDA tensors / streams to liblpx.  torch ships its own copy of the HIP runtime; when
+    it is initialised late, after liblpx has worked the GPU for a while through the system runtime, its device
+    discovery has been seen to fail on the test boxes ("no ROCm-capable device is detected").  Initialising it first
+    is harmless on a machine without a GPU (is_available() is False there)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def reference_vectors():
     with open(os.path.join(GOLDEN, "reference_vectors.json")) as f:
