@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py — simplex pivots/s of the MI355X-native pivot loop, with its HBM roofline and CPU baselines.
+"""bench.py — simplex pivots/s of the MI355X-native pivot loop, with its roofline, an oracle replay and CPU baselines.
 
     python bench.py --gpus 1 --steps 200 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -9,14 +9,18 @@ One "step" = one simplex pivot (entering scan + ratio test + tableau update + in
 LPState.java:274-320, :133-181) of a dense random LP:  A ~ U(0,1), b = (n/4) U(1,2), c ~ U(0,1), maximise
 (SURVEY §8d).  The default workload is BASELINE cfg4 (m=32768, n=16384, 4 GiB fp64 tableau): it is the
 configuration the metric's 1/2/4/8-GPU scaling is quoted on and it fits one GPU, so every N runs the SAME
-job ("scaling": "strong").  At N>1 the tableau is sharded by row blocks, one process per GPU, one RCCL
-all_gather of (8+n) doubles per pivot (linear_programming_solver_amd/sharded.py).
+job ("scaling": "strong").  At N>1 the tableau is cut into row blocks behind ONE lpx_multi handle (C ABI): rank 0
+drives all N GPUs, their persistent decision kernels exchange candidates and pivot rows by direct xGMI stores, the
+other ranks only join the barriers (`--multi-backend rccl`: round 1's one process per GPU + RCCL all_gather).
 
 The timed region starts with the tableau resident in HBM (upload excluded).  Rank 0 prints ONE JSON line.
-`roofline.achieved` = 16*m_local*n algorithmic bytes per row-update launch / that kernel's mean duration,
-measured with HIP events on the launch stream inside the timed region.  `cpu_baseline` = the decimal-15
-oracle (the reference's BigDecimal arithmetic, 4 threads as in pivotConcurrently) and `cpu_baseline_fp64` =
-the fp64 oracle on all host cores, both timed here on a bounded row-sample of the same tableau.
+`roofline`: the sweep / row-update launch is bounded below by one 16*m_local*n-byte pass at 8 TB/s and by its
+2*m_local*n*K unfusable fp64 operations at 39.3 T op/s; frac = the larger bound / the mean launch time measured with
+HIP events on the launch stream inside the timed region (<= 1), `bound` names the larger term (roofline_block).
+`parity_after_timed_region`: warm-up + steps pivots replayed on the fp64 oracle and compared bit for bit with what the
+timed handle holds.  `cpu_baseline` = the decimal-15 oracle (the reference's BigDecimal arithmetic, 4 threads as in
+pivotConcurrently) and `cpu_baseline_fp64` = the fp64 oracle on all host cores, both timed here on a bounded
+row-sample of the same tableau.  At N=1 the line also carries a `cfg3` object (BASELINE's single-GPU roofline config).
 """
 import argparse
 import json
