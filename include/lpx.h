@@ -127,7 +127,7 @@ typedef enum lpx_option {
   LPX_OPT_OVERLAP_MASK = 4,   /* 1 = CU-masked streams: 4 CUs of every XCD for the decisions, the rest for the sweep  */
   LPX_OPT_CHAIN_WGS = 5,      /* workgroups of the decision kernel; 0 = by size; always clamped to what is resident  */
   LPX_OPT_CHAIN_FENCES = 6,   /* grid barrier of the decision kernel: bit 0 release fence, bit 1 acquire fence       */
-  LPX_OPT_SWEEP_ROWS = 7,     /* rows per workgroup of the blocked sweep; 0 = by size                                */
+  LPX_OPT_SWEEP_ROWS = 7,     /* rows one workgroup of the blocked sweep walks down (multiple of 64); 0 = by size    */
   LPX_OPT_NT = 8,             /* non-temporal tableau loads/stores: -1 = by size, 0, 1                               */
   LPX_OPT_BATCH = 9,          /* one-pass loop: pivots issued between two host polls; 0 = by size                    */
   LPX_OPT_CHAIN_TRACE = 10,   /* 1 = keep phase timestamps of the last decision launch (lpx_state_read_chain_trace)  */
@@ -152,7 +152,7 @@ typedef struct lpx_state_info {
   int32_t sweep_xcd_mask;       /* likewise for the sampled workgroups of the last blocked sweep                   */
   int32_t overlapped;           /* 1: the last blocked loop ran decisions beside sweeps (two tableau buffers)      */
   int32_t nontemporal;          /* tableau accesses are non-temporal                                               */
-  int32_t sweep_rows;           /* rows per workgroup of the last blocked sweep                                    */
+  int32_t sweep_rows;           /* rows per workgroup (run length) of the last blocked sweep                       */
   int32_t reserved;
 } lpx_state_info;
 int lpx_state_get_info(lpx_state* s, lpx_state_info* out);

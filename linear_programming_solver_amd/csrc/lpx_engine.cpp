@@ -67,7 +67,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_OVERLAP_MASK", 1, 0, 1},          // LPX_OPT_OVERLAP_MASK
     {"LPX_CHAIN_WGS", 0, 0, lpxk::kChainMaxWgs},  // LPX_OPT_CHAIN_WGS
     {"LPX_CHAIN_FENCES", 2, 0, 3},          // LPX_OPT_CHAIN_FENCES
-    {"LPX_SWEEP_ROWS", 0, 0, 128},          // LPX_OPT_SWEEP_ROWS
+    {"LPX_SWEEP_ROWS", 0, 0, 8192},         // LPX_OPT_SWEEP_ROWS
     {"LPX_NT", -1, -1, 1},                  // LPX_OPT_NT
     {"LPX_BATCH", 0, 0, 4096},              // LPX_OPT_BATCH
     {"LPX_CHAIN_TRACE", 0, 0, 1},           // LPX_OPT_CHAIN_TRACE
@@ -197,7 +197,8 @@ int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t
   lpx_state* s = new lpx_state();
   s->device = device;
   s->m = m_local; s->n = n; s->n_cap = n_cap; s->row0 = row0; s->m_global = m_global;
-  const int64_t ld = std::max<int64_t>(16, round_up(n_cap, 16));
+  int64_t ld = std::max<int64_t>(16, round_up(n_cap, 16));
+  if (const char* e = getenv("LPX_EXPERIMENT_LD_PAD")) ld += round_up(atoll(e), 16);   // experiment only (row pitch vs HBM channels)
   const int64_t mp = std::max<int64_t>(2, round_up(m_local, 2)) + 2;
   s->B.ld = ld;
   memcpy(s->opt, env_defaults(), sizeof s->opt);
@@ -498,8 +499,8 @@ int ensure_block_ring(lpx_state* s) {
   HIP_TRY(hipMemsetAsync(s->R.chain_own_prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.chain_dbg, 5 * lpxk::kBlockMax * sizeof(long long)));
   HIP_TRY(hipMemsetAsync(s->R.chain_dbg, 0, 5 * lpxk::kBlockMax * sizeof(long long), s->stream));
-  HIP_TRY(hipMalloc((void**)&s->R.census, (lpxk::kChainMaxWgs + 2) * sizeof(unsigned)));
-  HIP_TRY(hipMemsetAsync(s->R.census, 0, (lpxk::kChainMaxWgs + 2) * sizeof(unsigned), s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.census, (lpxk::kChainMaxWgs + 2 + 1200) * sizeof(unsigned)));   // + room for diagnostic builds
+  HIP_TRY(hipMemsetAsync(s->R.census, 0, (lpxk::kChainMaxWgs + 2 + 1200) * sizeof(unsigned), s->stream));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));
@@ -584,9 +585,11 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
     }
     HIP_TRY(hipEventRecord(s->ev[s->ev_used], stream));
   }
+  // CUs the sweep's stream may use: all but the decisions' reserved ones on the masked overlap stream
+  const int cus = (stream == s->ov_sweep && s->ov_masked) ? device_cus(s) - s->ov_chain_cus : device_cus(s);
   s->info.sweep_rows = lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, (int)s->opt[LPX_OPT_SWEEP_ROWS],
                                                 s->nontemporal, stream, A_src, b_src,
-                                                sample ? s->ev[s->ev_used + 1] : nullptr);
+                                                sample ? s->ev[s->ev_used + 1] : nullptr, cus);
   if (sample) s->ev_used += 2;
   HIP_TRY(hipGetLastError());
   return 0;
@@ -890,6 +893,13 @@ extern "C" int lpx_state_get_info(lpx_state* s, lpx_state_info* out) {
   }
   *out = s->info;
   return 0;
+}
+
+// diagnostic builds (LPX_SWEEP_STAMPS): raw copy of the census buffer behind the sweep's sample word
+extern "C" int lpx_debug_read_census(lpx_state* s, uint32_t* out, int32_t count) {
+  if (!s || !out || !s->R.census || count < 0 || count > (int)lpxk::kChainMaxWgs + 2 + 1200) return LPX_BAD_ARGUMENT;
+  if (hipSetDevice(s->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return LPX_DEVICE_ERROR;
+  return hipMemcpy(out, s->R.census, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : LPX_DEVICE_ERROR;
 }
 
 extern "C" int lpx_state_read_chain_trace(lpx_state* s, int64_t* ticks, int32_t cap, int32_t* ndecisions) {

@@ -133,10 +133,11 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
 int chain_blocks_per_cu();
 // apply the valid leading pending pivots (at most K) in one pass
 // A_src / b_src != NULL: out of place — read the tableau and b there, write the updated ones to B.A / B.b
-// returns the rows per workgroup used
-int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
+// rows_per_wg: rows one workgroup walks down (multiple of 64; <= 0: by size and by `cus`, the CUs the stream may use,
+// 0 = the whole device); returns the value used.  after_sweep: recorded between the sweep and the fix-up.
+int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src = nullptr, const double* b_src = nullptr,
-                       hipEvent_t after_sweep = nullptr);  // after_sweep: recorded between the sweep and the fix-up
+                       hipEvent_t after_sweep = nullptr, int cus = 0);
 // phase 1 / restore helpers
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
 void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);

@@ -18,6 +18,7 @@
 #include "lpx_kernels.h"
 
 #include <limits.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -1415,7 +1416,10 @@ template <int K, int RB, int MODE>
 __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], const double (*sh_col)[kSweepMaxRows],
                                             int np, int r0) {
   if constexpr (MODE != kSweepSimple) {
-    constexpr int D = 2;  // read-ahead distance in steps (1, 3 and 4 measured the same or worse)
+#ifndef LPX_SWEEP_D
+#define LPX_SWEEP_D 2
+#endif
+    constexpr int D = LPX_SWEEP_D;  // read-ahead distance in steps (1, 3 and 4 measured the same or worse)
     d2 cc[D + 1][RB / 2];
 #pragma unroll
     for (int s = 0; s < D && s < K; ++s)
@@ -1462,10 +1466,11 @@ __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], cons
   }
 }
 
-// OOP: read the tableau from Asrc, write the updated one to A (same traffic; lets the NEXT block's decisions read
-// the un-updated tableau while this sweep streams — see blocked_loop_overlapped in lpx_engine.cpp).
+// The sweep for K <= 16: one workgroup per tile of rows_per_tile (16) rows x 512 columns.  With at most 16 pivot-row
+// slices per thread the kernel keeps three waves per SIMD and is HBM-bound (5.6 TB/s); the long-run form below, built
+// for K = 32, measured 14-20 % slower here (cfg4, K = 16, same box: 1.72-1.82 ms vs 1.51 ms) and is not used.
 template <int K, bool NT, bool OOP>
-__global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, const double* __restrict__ Asrc,
+__global__ __launch_bounds__(256) void k_update_tiles(double* __restrict__ A, const double* __restrict__ Asrc,
                                                       int64_t ld, int m_local,
                                                       const double* __restrict__ prow_ring,
                                                       const double* __restrict__ col_ring, int64_t mp,
@@ -1580,6 +1585,181 @@ __global__ __launch_bounds__(256) void k_update_multi(double* __restrict__ A, co
       }
     }
   }
+}
+
+// OOP: read the tableau from Asrc, write the updated one to A (same traffic; lets the NEXT block's decisions read
+// the un-updated tableau while this sweep streams — see blocked_loop_overlapped in lpx_engine.cpp).
+//
+// Work split (round 2): a workgroup owns one 512-column strip and a LONG run of rows (rows_per_wg, several hundred to
+// a few thousand) and walks down it in chunks of 64 rows.  Its 2K doubles of pivot-row slices per thread are loaded
+// ONCE; per chunk only the K x 64 multipliers (16 KiB at K = 32) are staged — into the other half of the LDS array
+// while the current chunk is computed, so a chunk boundary costs one workgroup barrier.  In-kernel timestamps of the
+// first version (one workgroup per 64-row tile: profiles/r02_sweep_stamps_before.txt) showed why: inside the batch
+// loop a wave spent 0.1 us of 2.2 us per batch waiting for its loads and the SIMD was ~94 % busy with the two waves'
+// arithmetic — but a tile's 16 batches took 35 us of the 59 us a workgroup slot was held: the rest was the prologue,
+// 128 KiB of pivot-row slices + 16 KiB of multipliers fetched from L2 / Infinity Cache for every 256 KiB of tableau.
+constexpr int kSweepChunk = 64;   // rows per chunk; the LDS array holds two chunks' multipliers
+#ifndef LPX_SWEEP_LB
+#define LPX_SWEEP_LB(K) 2   // waves per SIMD the register allocation is held to (two workgroups per CU)
+#endif
+static_assert(kSweepMaxRows == 2 * kSweepChunk, "sh_col is double-buffered by chunk");
+
+template <int K, bool NT, bool OOP>
+__global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                      int64_t ld, int m_local,
+                                                      const double* __restrict__ prow_ring,
+                                                      const double* __restrict__ col_ring, int64_t mp,
+                                                      const LpxCtl* __restrict__ ring, int kmax,
+                                                      int rows_per_wg, int nstrips, unsigned* census) {
+  __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
+  __shared__ int sh_np;
+  constexpr int CH = kSweepChunk;
+  // rows per batch (register budget: 2K doubles of pivot rows); K = 32 with 8 rows measured 13 % slower (r02)
+  constexpr int RB = (K <= 8) ? 8 : 4;
+  constexpr int NB = 2;                              // register buffers: one batch computed, one in flight
+  constexpr int PF = (K * CH + 255) / 256;           // multipliers of the next chunk held per thread meanwhile
+  const int strip = blockIdx.x % nstrips;
+  const int grp = blockIdx.x / nstrips;
+  const int cj = strip * 512 + 2 * threadIdx.x;
+  const bool act = cj < (int)ld;
+  const int r_begin = grp * rows_per_wg;
+  const int nrows = min(m_local, r_begin + rows_per_wg) - r_begin;
+  if (nrows <= 0) return;
+  // uniform run base (SGPRs) + 32-bit per-lane byte offset: one VGPR per address
+  char* const tile_base = reinterpret_cast<char*>(A + (int64_t)r_begin * ld + strip * 512);
+  const char* const src_base =
+      OOP ? reinterpret_cast<const char*>(Asrc + (int64_t)r_begin * ld + strip * 512) : tile_base;
+  const uint32_t row_bytes = (uint32_t)ld * 8u;  // the launcher checks rows_per_wg * ld * 8 < 2^32
+  const uint32_t off0 = threadIdx.x * 16u;
+
+  // Prologue, once per workgroup: the ring's flags, the first chunk's multipliers, the thread's slices of the K pivot
+  // rows and the first batch of rows are requested together — ONE memory round trip, not four.
+  bool ok = false;
+  if (threadIdx.x < 64) ok = (int)threadIdx.x < K && (int)threadIdx.x < kmax && ring[threadIdx.x].do_update != 0;
+  for (int idx = threadIdx.x; idx < K * CH; idx += 256) {
+    const int sidx = idx / CH, r = idx % CH;
+    sh_col[sidx][r] = (r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;  // slots >= np: never used
+  }
+  d2 pr[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s)
+    pr[s] = act ? *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj) : d2{0.0, 0.0};
+  // Full strips (all but possibly the last one of a row) take the pipelined path for their full batches.
+  const bool fast_geom = (strip + 1) * 512 <= (int)ld;
+  const int nfull_geom = fast_geom ? nrows / RB : 0;   // full batches of the whole run (chunks hold CH / RB each)
+  d2 xb[NB][RB];
+#pragma unroll
+  for (int u = 0; u + 1 < NB; ++u) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      xb[u][r] = d2{0.0, 0.0};
+      if (u < nfull_geom) {  // uniform
+        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(u * RB + r) * row_bytes));
+        xb[u][r] = NT ? __builtin_nontemporal_load(q) : *q;
+      }
+    }
+  }
+  if (threadIdx.x < 64) {
+    const unsigned long long mask = __ballot(ok);
+    if (threadIdx.x == 0) sh_np = (~mask == 0ull) ? 64 : (__ffsll((long long)~mask) - 1);
+  }
+  __syncthreads();  // chunk 0's multipliers and sh_np complete
+  const int np = sh_np;
+  if (np == 0 && !OOP) return;  // out of place: the tableau still has to be carried over
+
+  if (census && blockIdx.x % 61u == 0 && threadIdx.x == 0) atomicOr(census, 1u << xcc_id());  // placement sample
+#ifdef LPX_SWEEP_STAMPS   // diagnostic build only: lifetime of sampled workgroups
+  long long wg_t0 = wall_clock64();
+#endif
+
+  const int full = np > 0 ? nfull_geom : 0;   // batches of the pipelined path, numbered over the whole run
+  const int nchunks = (nrows + CH - 1) / CH;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int half = (ch & 1) * CH;                      // this chunk's half of sh_col
+    const int c_rows = min(CH, nrows - ch * CH);
+    // the next chunk's multipliers: requested now, parked in registers, stored into the other half at the end
+    double colpf[PF];
+    const bool more = ch + 1 < nchunks;
+    if (more) {
+      const int n_next = min(CH, nrows - (ch + 1) * CH);
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        const int sidx = idx / CH, r = idx % CH;
+        colpf[k] = (idx < K * CH && r < n_next) ? col_ring[(int64_t)sidx * mp + r_begin + (ch + 1) * CH + r] : 0.0;
+      }
+    }
+    // pipelined path: straight-line batches without any per-lane guard — the next batch's loads (possibly the next
+    // chunk's first rows: the run is contiguous) are in flight while this one runs its 2 np fp64 operations per entry
+    const int b_lo = ch * (CH / RB), b_hi = min(full, b_lo + CH / RB);
+    auto stream_batches = [&](auto mode) {
+      constexpr int MODE = decltype(mode)::value;
+#pragma unroll 1
+      for (int bt = b_lo; bt < b_hi; bt += NB) {   // b_lo is even: buffer u holds batch bt + u
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+          if (bt + u < b_hi) {  // uniform
+            const int r0 = (bt + u) * RB;
+            if (bt + u + NB - 1 < full) {  // request batch bt+u+NB-1 into the buffer that was stored last
+#pragma unroll
+              for (int r = 0; r < RB; ++r) {
+                const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(r0 + (NB - 1) * RB + r) * row_bytes));
+                xb[(u + NB - 1) % NB][r] = NT ? __builtin_nontemporal_load(q) : *q;
+              }
+            }
+            sweep_apply<K, RB, MODE>(xb[u], pr, sh_col, np, half + (r0 & (CH - 1)));
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+              d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+              if (NT) __builtin_nontemporal_store(xb[u][r], q); else *q = xb[u][r];
+            }
+          }
+        }
+      }
+    };
+    if (b_hi > b_lo) {
+      if (np == K) stream_batches(std::integral_constant<int, kSweepAll>{});
+      else stream_batches(std::integral_constant<int, kSweepGuarded>{});
+    }
+    // the rest of the chunk (an empty block carried over out of place, rows beyond the last full batch, the partial
+    // last strip): guarded
+    const int done_rows = (b_hi > b_lo ? b_hi - b_lo : 0) * RB;
+    for (int rr = done_rows; rr < c_rows; rr += RB) {
+      const int r0 = ch * CH + rr;
+      d2 y[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        y[r] = d2{0.0, 0.0};
+        if (rr + r < c_rows && act) {
+          const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+          y[r] = NT ? __builtin_nontemporal_load(q) : *q;
+        }
+      }
+      sweep_apply<K, RB, kSweepSimple>(y, pr, sh_col, np, half + rr);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        if (rr + r < c_rows && act) {
+          d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+          if (NT) __builtin_nontemporal_store(y[r], q); else *q = y[r];
+        }
+      }
+    }
+    if (more) {   // uniform: publish the next chunk's multipliers; everyone is done with the half they go into
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        if (idx < K * CH) sh_col[idx / CH][(CH - half) + idx % CH] = colpf[k];
+      }
+      __syncthreads();
+    }
+  }
+#ifdef LPX_SWEEP_STAMPS
+  if (census && blockIdx.x % 16u == 0 && blockIdx.x / 16u < 140 && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long* o = reinterpret_cast<long long*>(census + 8) + (blockIdx.x / 16u) * 2;
+    o[0] = wg_t0; o[1] = wall_clock64();
+  }
+#endif
 }
 
 // One pivot applied to one value with the reference's full case analysis (LPState.java:139-164): the value at
@@ -1921,47 +2101,100 @@ int chain_blocks_per_cu() {
 }
 
 template <int K>
-static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_tile, bool nt,
-                           const double* A_src, hipStream_t s) {
+static void launch_sweep_tiles(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_tile, bool nt,
+                               const double* A_src, hipStream_t s) {
   const int nstrips = (int)((B.ld + 511) / 512);
   const int ntiles = (m_local + rows_per_tile - 1) / rows_per_tile;
   const dim3 grid(nstrips * ntiles), block(256);
 #define LPX_LAUNCH_SWEEP(NT_, OOP_)                                                                              \
-  hipLaunchKernelGGL((k_update_multi<K, NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, \
+  hipLaunchKernelGGL((k_update_tiles<K, NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, \
                      R.mp, R.up, kmax, rows_per_tile, nstrips, R.census ? R.census + kChainMaxWgs : nullptr)
   if (A_src) { if (nt) LPX_LAUNCH_SWEEP(true, true); else LPX_LAUNCH_SWEEP(false, true); }
   else { if (nt) LPX_LAUNCH_SWEEP(true, false); else LPX_LAUNCH_SWEEP(false, false); }
 #undef LPX_LAUNCH_SWEEP
 }
 
-// rows_per_tile <= 0: chosen here from measurements (profiles/r01_sweep_rows.txt).  Up to K = 16 the sweep is
-// HBM-bound and 16-row tiles stream best (larger tiles widen the set of DRAM pages in flight: -10 %).  At K = 32
-// it is co-limited by the fp64 VALU, the per-workgroup prologue (2K doubles of pivot rows per thread) weighs more,
-// and 64-row tiles win (+20 % over 16) as long as the grid still has a few thousand workgroups.
-int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_tile,
-                       bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep) {
-  if (K < 1) return 0;
-  if (rows_per_tile <= 0) {
-    const int64_t nstrips = (B.ld + 511) / 512;
-    rows_per_tile = 16;
-    if (K > 16) {
-      for (int rows : {64, 32}) {
-        if ((int64_t)((m_local + rows - 1) / rows) * nstrips >= 4096) { rows_per_tile = rows; break; }
-      }
-    }
+template <int K>
+static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
+                           const double* A_src, hipStream_t s) {
+  const int nstrips = (int)((B.ld + 511) / 512);
+  const int ngroups = (m_local + rows_per_wg - 1) / rows_per_wg;
+  const dim3 grid(nstrips * ngroups), block(256);
+#define LPX_LAUNCH_SWEEP(NT_, OOP_)                                                                              \
+  hipLaunchKernelGGL((k_update_multi<K, NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, \
+                     R.mp, R.up, kmax, rows_per_wg, nstrips, R.census ? R.census + kChainMaxWgs : nullptr)
+  if (A_src) { if (nt) LPX_LAUNCH_SWEEP(true, true); else LPX_LAUNCH_SWEEP(false, true); }
+  else { if (nt) LPX_LAUNCH_SWEEP(true, false); else LPX_LAUNCH_SWEEP(false, false); }
+#undef LPX_LAUNCH_SWEEP
+}
+
+// Rows per workgroup of the sweep (a multiple of its 64-row chunk).  A workgroup pays its prologue (the 2K doubles of
+// pivot-row slices per thread, ~K x 1.5 rows' worth of traffic) once per run, so runs should be long; but the grid
+// is dealt in rounds of `slots` workgroups (two per CU the stream may use) and the last round should be full.
+// Chosen by cost = rounds x (rows + prologue): several rounds of long runs.
+static int choose_sweep_rows(int m_local, int64_t ld, int K, int cus) {
+  const int64_t nstrips = (ld + 511) / 512;
+  const int64_t slots = std::max(1, 2 * cus);
+  const int prologue_rows = std::max(8, (K * 3) / 2);
+  int best_rows = kSweepChunk;
+  int64_t best_cost = INT64_MAX;
+  const int max_rows = (int)std::min<int64_t>(4096, (((int64_t)1 << 32) - 1) / (ld * 8) / kSweepChunk * kSweepChunk);
+  for (int rows = kSweepChunk; rows <= std::max(kSweepChunk, max_rows); rows += kSweepChunk) {
+    const int64_t groups = (m_local + rows - 1) / rows;
+    const int64_t rounds = (nstrips * groups + slots - 1) / slots;
+    // one round of huge runs leaves no slack for uneven CUs: ask for at least three rounds when there is enough work
+    const int64_t want_rounds = (int64_t)m_local * nstrips >= 3 * slots * kSweepChunk ? 3 : 1;
+    const int64_t cost = std::max(rounds, want_rounds) * (rows + prologue_rows);
+    if (cost < best_cost || (cost == best_cost && rows > best_rows)) { best_cost = cost; best_rows = rows; }
+    if (groups == 1) break;
   }
-  rows_per_tile = std::max(8, std::min(rows_per_tile, kSweepMaxRows)) & ~7;  // rows go four or eight at a time
-  while (rows_per_tile > 8 && (int64_t)rows_per_tile * B.ld * 8 >= (int64_t)1 << 32) rows_per_tile -= 8;  // 32-bit offsets
-  if (K <= 2) launch_sweep_k<2>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
-  else if (K <= 4) launch_sweep_k<4>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
-  else if (K <= 8) launch_sweep_k<8>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
-  else if (K <= 16) launch_sweep_k<16>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
-  else launch_sweep_k<32>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+  return best_rows;
+}
+
+// rows_per_wg <= 0: chosen here (see choose_sweep_rows); cus: CUs the stream may use (0: the whole device)
+int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
+                       bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep,
+                       int cus) {
+  if (K < 1) return 0;
+  if (cus <= 0) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  if (K <= 16) {
+    // tiles of a few rows (k_update_tiles): up to K = 16 the sweep is HBM-bound and 16-row tiles stream best
+    // (profiles/r01_sweep_rows.txt: larger tiles widen the set of DRAM pages in flight, -10 %)
+    int rows_per_tile = rows_per_wg <= 0 ? 16 : rows_per_wg;
+    rows_per_tile = std::max(8, std::min(rows_per_tile, kSweepMaxRows)) & ~7;  // rows go four or eight at a time
+    while (rows_per_tile > 8 && (int64_t)rows_per_tile * B.ld * 8 >= (int64_t)1 << 32) rows_per_tile -= 8;  // 32-bit offsets
+    if (K <= 2) launch_sweep_tiles<2>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+    else if (K <= 4) launch_sweep_tiles<4>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+    else if (K <= 8) launch_sweep_tiles<8>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+    else launch_sweep_tiles<16>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+    rows_per_wg = rows_per_tile;
+  } else if (K < kMaxBlock) {
+    // a partly filled block of 17..31 pivots (the tail of a pivot budget): the tile kernel's guarded path took such
+    // blocks faster than the long-run kernel's (cfg3, 20 pivots, same box: 490 vs 615 us); 64-row tiles as long as the
+    // grid keeps a few thousand workgroups (profiles/r01_sweep_rows.txt)
+    const int64_t nstrips = (B.ld + 511) / 512;
+    int rows_per_tile = 16;
+    for (int rows : {64, 32})
+      if ((int64_t)((m_local + rows - 1) / rows) * nstrips >= 4096) { rows_per_tile = rows; break; }
+    while (rows_per_tile > 8 && (int64_t)rows_per_tile * B.ld * 8 >= (int64_t)1 << 32) rows_per_tile -= 8;
+    launch_sweep_tiles<32>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
+    rows_per_wg = rows_per_tile;
+  } else {
+    // long runs of rows per workgroup (k_update_multi): the 2K doubles of pivot-row slices are fetched once per run
+    if (rows_per_wg <= 0) rows_per_wg = choose_sweep_rows(m_local, B.ld, K, cus);
+    rows_per_wg = std::max(kSweepChunk, (rows_per_wg + kSweepChunk - 1) / kSweepChunk * kSweepChunk);
+    while (rows_per_wg > kSweepChunk && (int64_t)rows_per_wg * B.ld * 8 >= (int64_t)1 << 32) rows_per_wg -= kSweepChunk;  // 32-bit offsets
+    launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s);
+  }
   if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
                      R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b);
-  return rows_per_tile;
+  return rows_per_wg;
 }
 
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {

@@ -734,7 +734,7 @@ def test_blocked_pivoting_is_bit_identical(lps, oracle, shape, block):
     {"chain_wgs": 1}, {"chain_wgs": 3},          # several rows / columns per thread in k_block_chain
     {"chain_wgs": 7, "overlap": 0},
     {"chain_fences": 3},                         # release + acquire at every grid barrier (the conservative form)
-    {"sweep_rows": 8}, {"sweep_rows": 128},
+    {"sweep_rows": 64}, {"sweep_rows": 192}, {"sweep_rows": 4096},   # one chunk / three chunks / one run per strip
 ], ids=lambda k: ",".join("%s=%s" % kv for kv in sorted(k.items())))
 def test_blocked_loop_forms_are_bit_identical(lps, oracle, knobs):
     """Every form of the blocked loop (default: decisions one block ahead of out-of-place sweeps) gives the
