@@ -1615,8 +1615,15 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
   __shared__ int sh_np;
   constexpr int CH = kSweepChunk;
   // rows per batch (register budget: 2K doubles of pivot rows); K = 32 with 8 rows measured 13 % slower (r02)
-  constexpr int RB = (K <= 8) ? 8 : 4;
-  constexpr int NB = 2;                              // register buffers: one batch computed, one in flight
+#ifndef LPX_STRIP_RB
+#define LPX_STRIP_RB 4
+#endif
+#ifndef LPX_STRIP_NB
+#define LPX_STRIP_NB 2
+#endif
+  constexpr int RB = (K <= 8) ? 8 : LPX_STRIP_RB;
+  constexpr int NB = LPX_STRIP_NB;                   // register buffers: one batch computed, NB - 1 in flight
+  static_assert((CH / RB) % NB == 0, "a chunk holds a whole number of buffer rotations");
   constexpr int PF = (K * CH + 255) / 256;           // multipliers of the next chunk held per thread meanwhile
   const int strip = blockIdx.x % nstrips;
   const int grp = blockIdx.x / nstrips;
