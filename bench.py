@@ -366,26 +366,67 @@ def main():
         return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
                 "pivots_per_launch": pivots_per_launch, "upload_s": t_up, "info": st.info()}
 
+    def peer_selfcheck(devices):
+        """Before anything is timed on a device set that has never been exercised together: a small LP through the
+        multi-device handle must leave exactly the bits the one-device handle leaves (70 pivots: two blocks + a tail,
+        the owner of the leaving row changing from decision to decision)."""
+        from linear_programming_solver_amd import LPMulti
+        rng = np.random.default_rng(7)
+        ms, ns = 64 * len(devices), 1024
+        As, bs, cs = rng.random((ms, ns)), (ns / 4.0) * (1.0 + rng.random(ms)), rng.random(ns)
+        one = LPState(As, bs, cs, device=devices[0], block=16)
+        many = LPMulti(As, bs, cs, devices=devices, block=16)
+        try:
+            r1 = one.simplex_loop(max_pivots=70)
+            r2 = many.simplex_loop(max_pivots=70)
+            g1, g2 = one.read(), many.read()
+            same = r1[:2] == r2[:2] and all(np.array_equal(np.asarray(x).view(np.uint64), np.asarray(y).view(np.uint64))
+                                            for x, y in zip(g1[:3], g2[:3])) and g1[3] == g2[3] and list(g1[4]) == list(g2[4])
+            if not same:
+                raise RuntimeError("lpx_multi self-check: the sharded result differs from the one-device result")
+        finally:
+            one.close()
+            many.close()
+
     def run_peer(Aw, bw, cw):
-        """the same protocol on the lpx_multi handle: rank 0 drives all shards, every rank joins the barriers"""
+        """the same protocol on the lpx_multi handle: rank 0 drives all shards, every rank joins the barriers.  Any
+        failure on rank 0 (the peer path has not run on real multi-GPU hardware before) is reported to all ranks,
+        which then fall back to the RCCL form."""
         from linear_programming_solver_amd import LPMulti
         mt, t_up, block, launches, avg_ms, ppl, info = None, 0.0, 0, 0, float("nan"), float("nan"), None
+        err = None
         if rank == 0:
-            devices = list(range(world)) if world > 1 else [local_rank] * nshards
-            t_up = time.perf_counter()
-            mt = LPMulti(Aw, bw, cw, devices=devices, options=options)
-            t_up = time.perf_counter() - t_up
-            status, piv, _ = mt.simplex_loop(max_pivots=W)
-            assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
-            mt.profile_enable(1 if args.event_every > 0 else 0)
+            try:
+                devices = list(range(world)) if world > 1 else [local_rank] * nshards
+                if world > 1:
+                    peer_selfcheck(devices)
+                t_up = time.perf_counter()
+                mt = LPMulti(Aw, bw, cw, devices=devices, options=options)
+                t_up = time.perf_counter() - t_up
+                status, piv, _ = mt.simplex_loop(max_pivots=W)
+                assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
+                mt.profile_enable(1 if args.event_every > 0 else 0)
+            except Exception as ex:   # noqa: BLE001 - reported, then the RCCL form is used
+                err = "%s: %s" % (type(ex).__name__, ex)
         barrier()
         t0 = time.perf_counter()
-        if rank == 0:
-            status, piv, _ = mt.simplex_loop(max_pivots=K)
+        if rank == 0 and err is None:
+            try:
+                status, piv, _ = mt.simplex_loop(max_pivots=K)
+                assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
+            except Exception as ex:   # noqa: BLE001
+                err = "%s: %s" % (type(ex).__name__, ex)
         barrier()
         elapsed = time.perf_counter() - t0
+        if dist is not None:
+            box = [err]
+            dist.broadcast_object_list(box, src=0)
+            err = box[0]
+        if err is not None:
+            if mt is not None:
+                mt.close()
+            return {"error": err}
         if rank == 0:
-            assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
             launches, kernel_ms = mt.profile_read(0)
             mt.profile_enable(0)
             info = mt.info()
@@ -399,8 +440,28 @@ def main():
         return {"st": mt, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
                 "pivots_per_launch": ppl, "upload_s": t_up, "info": info}
 
+    fallback_reason = None
     if peer:
         r1_ = run_peer(A, b, c)
+        if "error" in r1_:
+            if world == 1:
+                raise SystemExit("lpx_multi rehearsal failed: " + r1_["error"])
+            # the documented alternative: one process per GPU, one RCCL all_gather per decision
+            fallback_reason = r1_["error"]
+            sys.stderr.write("bench.py: lpx_multi path failed (%s); falling back to --multi-backend rccl\n" % fallback_reason)
+            peer, sharded = False, True
+            dist.barrier()
+            dist.destroy_process_group()
+            pg_opts = None
+            try:
+                pg_opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                pg_opts = None
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank), pg_options=pg_opts)
+            r0, r1 = row_block(m, world, rank)
+            A, b, c = gen_rows(m, n, args.seed, r0, r1)
+    if peer:
         eng = st = r1_["st"]
         elapsed, block, launches, avg_ms = r1_["elapsed"], r1_["block"], r1_["launches"], r1_["avg_ms"]
         pivots_per_launch, t_up, info = r1_["pivots_per_launch"], r1_["upload_s"], r1_["info"]
@@ -478,6 +539,9 @@ def main():
         }
         if info is not None:   # what the engine actually did: grid of the decision kernel, its residency bound, CU masks
             line["engine"] = info
+        if world > 1:
+            line["multi_backend"] = "peer (lpx_multi)" if peer else ("rccl" if fallback_reason is None else
+                                                                     "rccl, after the lpx_multi path failed: " + fallback_reason)
         if (peer or (world == 1 and not sharded)) and not args.no_parity:
             # the checker: the same LP replayed on the fp64 oracle for warm-up + steps pivots (outside the timed region)
             line["parity_after_timed_region"] = parity_after(st, A, b, c, W + K, m, n, host_cores(), args.parity_max_pivots)

@@ -197,8 +197,7 @@ int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t
   lpx_state* s = new lpx_state();
   s->device = device;
   s->m = m_local; s->n = n; s->n_cap = n_cap; s->row0 = row0; s->m_global = m_global;
-  int64_t ld = std::max<int64_t>(16, round_up(n_cap, 16));
-  if (const char* e = getenv("LPX_EXPERIMENT_LD_PAD")) ld += round_up(atoll(e), 16);   // experiment only (row pitch vs HBM channels)
+  const int64_t ld = std::max<int64_t>(16, round_up(n_cap, 16));
   const int64_t mp = std::max<int64_t>(2, round_up(m_local, 2)) + 2;
   s->B.ld = ld;
   memcpy(s->opt, env_defaults(), sizeof s->opt);
