@@ -509,7 +509,7 @@ int ensure_block_ring(lpx_state* s) {
 }
 
 // The second tableau / b of the out-of-place forms (pipeline 2 of the shards, the overlapped blocked loop).
-static int ensure_spare_tableau(lpx_state* s) {
+int ensure_spare_tableau(lpx_state* s) {
   if (s->A2) return 0;
   const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
   // 4 KiB skew between the two buffers: measured 346 us vs 354 us per cfg3 update with none (the read and the
@@ -617,7 +617,7 @@ lpxk::BlockRing ring_half(const lpx_state* s, int h) {
 #define LPX_CHAIN_CUS_PER_XCD 4
 #endif
 static constexpr int kChainCusPerXcd = LPX_CHAIN_CUS_PER_XCD;
-static int ensure_overlap_streams(lpx_state* s) {
+int ensure_overlap_streams(lpx_state* s) {
   if (s->ov_chain) return 0;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, s->device));

@@ -86,6 +86,8 @@ int upload_common(lpx_state* s, const double* A, int64_t lda, const double* b, c
 void init_ctl(lpx_state* s, double v);
 int set_running(lpx_state* s, int64_t max_pivots, int32_t track);
 int ensure_block_ring(lpx_state* s);
+int ensure_spare_tableau(lpx_state* s);     // the second tableau / b of the out-of-place forms
+int ensure_overlap_streams(lpx_state* s);   // ov_chain / ov_sweep (CU-masked when possible) and their events
 // hipMalloc, or fine-grained device memory when peers store into the buffer while a kernel of this device reads it
 hipError_t peer_visible_malloc(const lpx_state* s, void** ptr, size_t bytes);
 int32_t state_n(const lpx_state* s);

@@ -854,7 +854,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
     unsigned spins = 0;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       LPX_BARRIER_SLEEP;
-      if (++spins > (1u << 22)) { *sh_fail = 1; break; }
+      if (++spins > (1u << 22)) { *sh_fail = 1; break; }   // 1: grid barrier
     }
     if (fences & 2) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         unsigned spins = 0;
         while (__hip_atomic_load(&rec->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xtag) {
           LPX_BARRIER_SLEEP;
-          if (++spins > (1u << 22)) { sh_fail = 1; break; }
+          if (++spins > (1u << 22)) { sh_fail = 2 + 16 * tid; break; }   // 2: a peer's candidate record
         }
         if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         theirs.ratio = ld_sys(&rec->ratio);
@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         theirs_b = ld_sys(&rec->bi);
       }
       w = rr_block_min(theirs, sh_rr);
-      if (sh_fail) { if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); } return; }
+      if (sh_fail) { if (lead) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
       if (w.row != INT_MAX && tid < P.n_dev && theirs.row == w.row) { sh_win[0] = theirs_a; sh_win[1] = theirs_b; }
       __syncthreads();
     }
@@ -1199,12 +1199,12 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
           unsigned spins = 0;
           while (__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)xtag) {
             LPX_BARRIER_SLEEP;
-            if (++spins > (1u << 22)) { sh_fail = 1; break; }
+            if (++spins > (1u << 22)) { sh_fail = 3 + 16 * tid; break; }   // 3: the owner's arrival word
           }
           if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         }
         __syncthreads();
-        if (sh_fail) { if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); } return; }
+        if (sh_fail) { if (lead) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
       }
     }
     // Column ownership: with the hand-off, workgroup 0 owns slots 0..255 and nothing else (it is on everybody's
@@ -1329,12 +1329,12 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
           rec = __hip_atomic_load(P.hand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(rec >> 32) == want) break;
           LPX_BARRIER_SLEEP;
-          if (++spins > (1u << 22)) { sh_fail = 1; break; }
+          if (++spins > (1u << 22)) { sh_fail = 4; break; }   // 4: workgroup 0's hand-off word
         }
         sh_restart = (int)(unsigned)(rec & 0xffffffffu) - 2;
       }
       __syncthreads();
-      if (sh_fail) { if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); } return; }
+      if (sh_fail) { if (lead) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
       e_next = sh_restart;
       __syncthreads();  // sh_restart is reused by the next phase
     }

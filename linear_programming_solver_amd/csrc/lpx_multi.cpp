@@ -223,6 +223,130 @@ extern "C" int lpx_multi_pivot(lpx_multi* M, int32_t entering, int32_t leaving) 
   return result;
 }
 
+// After a loop: the replicated loop state must agree on every device; hand it to the caller.
+static int multi_finish_loop(lpx_multi* M, int64_t* pivots_done, int32_t* status, int32_t* track_slot) {
+  const int G = M->n_dev;
+  for (int r = 0; r < G; r++) {
+    HIP_TRY(hipSetDevice(M->device[r]));
+    if (int r2 = sync_ctl_to_host(M->sh[r])) return r2;
+  }
+  const LpxCtl& c0 = *M->sh[0]->h_ctl;
+  for (int r = 0; r < G; r++)
+    if (M->sh[r]->h_ctl->status == LPX_DEVICE_ERROR)
+      return fail(LPX_DEVICE_ERROR, "decision kernel of shard " + std::to_string(r) + ": a wait hit its spin bound (code " +
+                  std::to_string(M->sh[r]->h_ctl->reserved) + ": 1 grid barrier, 2 a peer's candidate, 3 the owner's row, "
+                  "4 hand-off; + 16 x lane + 1000 x decision).  Shards that share a GPU need one hardware queue per "
+                  "stream: GPU_MAX_HW_QUEUES");
+  for (int r = 1; r < G; r++) {
+    const LpxCtl& cr = *M->sh[r]->h_ctl;
+    if (cr.status != c0.status || cr.pivots != c0.pivots || cr.track != c0.track || memcmp(&cr.v, &c0.v, sizeof(double)) != 0)
+      return fail(LPX_DEVICE_ERROR, "lpx_multi_simplex_loop: the replicated loop state diverged between devices");
+  }
+  if (pivots_done) *pivots_done = c0.pivots;
+  if (status) *status = c0.status;
+  if (track_slot) *track_slot = c0.track;
+  if (c0.status == LPX_DIVIDE_BY_ZERO) return fail(LPX_DIVIDE_BY_ZERO, "pivot element is zero");
+  return 0;
+}
+
+static int multi_loop_overlapped(lpx_multi* M, int K, int64_t max_pivots, int want_wgs, int fences, bool trace, int dantzig,
+                                 int64_t* pivots_done, int32_t* status, int32_t* track_slot) {
+  const int G = M->n_dev;
+  // the decision kernels' grid: the same on every device, within what the CUs of each shard's decision stream hold
+  // (shards that share a GPU share those CUs)
+  int wgs = want_wgs;
+  for (int r = 0; r < G; r++) {
+    int same = 0;
+    for (int q = 0; q < G; q++) same += M->device[q] == M->device[r];
+    HIP_TRY(hipSetDevice(M->device[r]));
+    wgs = std::min(wgs, clamp_chain_wgs(M->sh[r], want_wgs, std::max(1, M->sh[r]->ov_chain_cus / same)));
+  }
+  std::vector<double*> Abuf0(G), Abuf1(G), bbuf0(G), bbuf1(G);
+  for (int r = 0; r < G; r++) {
+    lpx_state* s = M->sh[r];
+    HIP_TRY(hipSetDevice(M->device[r]));
+    s->info.chain_wgs = wgs; s->info.overlapped = 1; s->info.chain_stream_masked = s->ov_masked ? 1 : 0;
+    Abuf0[r] = s->B.A; Abuf1[r] = s->A2; bbuf0[r] = s->B.b; bbuf1[r] = s->b2;
+    // the seed (entering scan) ran on the shard's own stream: both work streams continue after it
+    HIP_TRY(hipEventRecord(s->ev_ov_join[0], s->stream));
+    HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_join[0], 0));
+    HIP_TRY(hipStreamWaitEvent(s->ov_sweep, s->ev_ov_join[0], 0));
+  }
+  int64_t decided = 0;
+  int nb_prev = 0, nblk = 0;
+  auto issue_block = [&](int k) -> int {   // 1: the budget is spent, nothing issued
+    const int nb = block_len(K, max_pivots, decided);
+    if (nb <= 0) return 1;
+    const int h = k & 1;
+    const bool probe_only = max_pivots >= 0 && decided == max_pivots;   // can only report the end: nothing to sweep
+    for (int r = 0; r < G; r++) {
+      lpx_state* s = M->sh[r];
+      HIP_TRY(hipSetDevice(M->device[r]));
+      if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h], 0));   // sweep k-2: its input, its ring half
+      Buffers Brd = s->B;
+      const int src = k == 0 ? 0 : (k - 1) & 1;
+      Brd.A = src ? Abuf1[r] : Abuf0[r];
+      Brd.b = src ? bbuf1[r] : bbuf0[r];
+      lpxk::MgPeers P = peers_of(M, r);
+      P.mail_slot0 = (int)(decided & 1);
+      lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0, M->seq, dantzig, wgs,
+                               fences, trace, M->d_snap[r] + h, s->ov_chain, &P);
+      s->chain_nb_last = nb;
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(s->ev_ov_chain[h], s->ov_chain));
+    }
+    M->seq++;
+    if (!probe_only) {
+      for (int r = 0; r < G; r++) {
+        lpx_state* s = M->sh[r];
+        HIP_TRY(hipSetDevice(M->device[r]));
+        HIP_TRY(hipStreamWaitEvent(s->ov_sweep, s->ev_ov_chain[h], 0));
+        Buffers Bdst = s->B;
+        Bdst.A = h ? Abuf0[r] : Abuf1[r];   // buffer h -> buffer h ^ 1
+        Bdst.b = h ? bbuf0[r] : bbuf1[r];
+        if (int rc = launch_sweep_profiled(s, nb, s->ov_sweep, Bdst, ring_half(s, h), h ? Abuf1[r] : Abuf0[r],
+                                           h ? bbuf1[r] : bbuf0[r]))
+          return rc;
+        HIP_TRY(hipEventRecord(s->ev_ov_sweep[h], s->ov_sweep));
+      }
+      nb_prev = nb;
+      nblk = k + 1;
+    }
+    decided += nb;
+    return 0;
+  };
+  int rc = issue_block(0);
+  if (rc == 1) rc = 0;
+  for (int k = 1; rc == 0; k++) {
+    const int r1 = issue_block(k);
+    if (r1 != 0 && r1 != 1) { rc = r1; break; }
+    bool running = true;
+    for (int r = 0; r < G && rc == 0; r++) {
+      const hipError_t e = hipEventSynchronize(M->sh[r]->ev_ov_chain[(k - 1) & 1]);
+      if (e != hipSuccess) { rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e)); break; }
+      if (M->h_snap[2 * r + ((k - 1) & 1)].status != lpxk::kRunning) running = false;
+    }
+    if (rc || !running || r1 == 1) break;
+  }
+  // join: every shard's own stream continues after both work streams; the result lives in buffer nblk & 1
+  for (int r = 0; r < G; r++) {
+    lpx_state* s = M->sh[r];
+    (void)hipSetDevice(M->device[r]);
+    (void)hipEventRecord(s->ev_ov_join[1], s->ov_chain);
+    (void)hipEventRecord(s->ev_ov_join[2], s->ov_sweep);
+    (void)hipStreamWaitEvent(s->stream, s->ev_ov_join[1], 0);
+    (void)hipStreamWaitEvent(s->stream, s->ev_ov_join[2], 0);
+    if (nblk & 1) {
+      std::swap(s->B.A, s->A2);
+      std::swap(s->B.b, s->b2);
+    }
+    const hipError_t e = hipStreamSynchronize(s->stream);
+    if (rc == 0 && e != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e));
+  }
+  if (rc) return rc;
+  return multi_finish_loop(M, pivots_done, status, track_slot);
+}
+
 // The loop of LPSolver.simplex (LPSolver.java:101-107) over the shards: blocks of K decisions (one persistent launch
 // per device, exchanging among themselves), then one sweep per device.
 extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t* pivots_done, int32_t* status,
@@ -264,6 +388,25 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
   const int fences = M->distinct_devices ? 3 : (int)M->sh[0]->opt[LPX_OPT_CHAIN_FENCES];
   const bool trace = M->sh[0]->opt[LPX_OPT_CHAIN_TRACE] != 0;
   const int dantzig = M->sh[0]->pricing == 1;
+
+  // Decisions one block ahead of the sweeps, as on one GPU (lpx_engine.cpp blocked_loop_overlapped): every shard
+  // keeps two tableau buffers; the decision kernels of block k read the buffers sweep k-1 reads (its pivots are
+  // pending ones for them, like their own) and run beside it on their own streams.
+  if (M->sh[0]->opt[LPX_OPT_OVERLAP] != 0) {
+    bool ok = true;
+    for (int r = 0; r < G && ok; r++) {
+      HIP_TRY(hipSetDevice(M->device[r]));
+      // Shards that share a GPU (rehearsal) get plain streams: streams created with IDENTICAL CU masks were seen to
+      // be served by one hardware queue, and two decision kernels that wait for each other must not queue behind
+      // one another (the wait then runs into its spin bound).
+      int same = 0;
+      for (int q = 0; q < G; q++) same += M->device[q] == M->device[r];
+      if (same > 1 && !M->sh[r]->ov_chain) M->sh[r]->opt[LPX_OPT_OVERLAP_MASK] = 0;
+      ok = ensure_spare_tableau(M->sh[r]) == 0 && ensure_overlap_streams(M->sh[r]) == 0;
+    }
+    if (ok) return multi_loop_overlapped(M, K, max_pivots, want, fences, trace, dantzig, pivots_done, status, track_slot);
+    (void)hipGetLastError();   // no room for the second tableau: the serial form below
+  }
 
   int64_t decided = 0;
   auto issue_block = [&](int slot) -> int {
@@ -320,26 +463,7 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
     if (rc == 0 && e != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e));
   }
   if (rc) return rc;
-  // the replicated loop state must agree
-  for (int r = 0; r < G; r++) {
-    HIP_TRY(hipSetDevice(M->device[r]));
-    if (int r2 = sync_ctl_to_host(M->sh[r])) return r2;
-  }
-  const LpxCtl& c0 = *M->sh[0]->h_ctl;
-  for (int r = 0; r < G; r++)
-    if (M->sh[r]->h_ctl->status == LPX_DEVICE_ERROR)
-      return fail(LPX_DEVICE_ERROR, "decision kernel of shard " + std::to_string(r) + ": a peer did not answer within the "
-                  "spin bound (shards that share a GPU need one hardware queue each: GPU_MAX_HW_QUEUES)");
-  for (int r = 1; r < G; r++) {
-    const LpxCtl& cr = *M->sh[r]->h_ctl;
-    if (cr.status != c0.status || cr.pivots != c0.pivots || cr.track != c0.track || memcmp(&cr.v, &c0.v, sizeof(double)) != 0)
-      return fail(LPX_DEVICE_ERROR, "lpx_multi_simplex_loop: the replicated loop state diverged between devices");
-  }
-  if (pivots_done) *pivots_done = c0.pivots;
-  if (status) *status = c0.status;
-  if (track_slot) *track_slot = c0.track;
-  if (c0.status == LPX_DIVIDE_BY_ZERO) return fail(LPX_DIVIDE_BY_ZERO, "pivot element is zero");
-  return 0;
+  return multi_finish_loop(M, pivots_done, status, track_slot);
 }
 
 extern "C" int lpx_multi_read(lpx_multi* M, double* A, int64_t lda, double* b, double* c, double* v, int32_t* perm) {

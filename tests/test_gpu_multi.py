@@ -42,14 +42,16 @@ def dense_lp(m, n, seed):
     return rng.random((m, n)), (n / 4.0) * (1.0 + rng.random(m)), rng.random(n)
 
 
+@pytest.mark.parametrize("overlap", [1, 0], ids=["decisions-beside-sweeps", "serial"])
 @pytest.mark.parametrize("ndev", [1, 2, 3, 4])
 @pytest.mark.parametrize("shape,block", [((64, 100), 4), ((257, 513), 16), ((1000, 260), 32), ((9, 2100), 8)])
-def test_multi_loop_matches_oracle(lps, oracle, ndev, shape, block):
+def test_multi_loop_matches_oracle(lps, oracle, ndev, shape, block, overlap):
     """Budgets that are not multiples of the block, resumed loops, a run to optimality — every intermediate state of
-    the sharded tableau (rows gathered from the shards) equals the oracle's."""
+    the sharded tableau (rows gathered from the shards) equals the oracle's.  Both host loops: the decisions of block
+    k+1 beside the (out-of-place) sweeps of block k on every shard, and decisions-then-sweep in place."""
     m, n = shape
     A, b, c = dense_lp(m, n, seed=11 * m + n)
-    mt = lps.LPMulti(A, b, c, devices=[0] * ndev, block=block)
+    mt = lps.LPMulti(A, b, c, devices=[0] * ndev, block=block, options={"overlap": overlap})
     ref = oracle.State(A, b, c, kind=oracle.FP64)
     for budget in (1, block, 2 * block + 3, 0, 5 * block - 1, -1):
         status, pivots, _ = mt.simplex_loop(max_pivots=budget)
@@ -66,7 +68,7 @@ def test_multi_wide_decision_kernels_side_by_side(lps, oracle, fences):
     decision to decision.  Both exchange forms (fence-free, release + acquire)."""
     m, n = 4096, 8192
     A, b, c = dense_lp(m, n, seed=4)
-    mt = lps.LPMulti(A, b, c, devices=[0, 0, 0, 0], block=32, options={"chain_fences": fences})
+    mt = lps.LPMulti(A, b, c, devices=[0, 0, 0, 0], block=32, options={"chain_fences": fences, "overlap": 0})
     ref = oracle.State(A, b, c, kind=oracle.FP64)
     for budget in (100, 33):
         status, pivots, _ = mt.simplex_loop(max_pivots=budget)
@@ -75,6 +77,16 @@ def test_multi_wide_decision_kernels_side_by_side(lps, oracle, fences):
         assert_state_bits_equal(mt.read(), ref.read(), "fences %d budget %d" % (fences, budget))
     info = mt.info()
     assert 4 * info["chain_wgs"] <= 4 * info["chain_resident_max"] and info["chain_wgs"] >= 8, info
+    mt.close()
+    # the same tableau with the decisions one block ahead of the sweeps (three shards: nine streams on one GPU)
+    mt = lps.LPMulti(A, b, c, devices=[0, 0, 0], block=32, options={"chain_fences": fences})
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (100, 33):
+        status, pivots, _ = mt.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget, threads=16)
+        assert (status, pivots) == (want["status"], want["pivots"]) == (9, budget)
+        assert_state_bits_equal(mt.read(), ref.read(), "overlapped, fences %d budget %d" % (fences, budget))
+    assert mt.info()["overlapped"] == 1
     mt.close()
 
 
