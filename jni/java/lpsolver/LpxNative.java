@@ -23,6 +23,11 @@ final class LpxNative {
   static native int solve(int m, int n, double[] a, double[] b, double[] c, boolean maximize,
                           int[] restoreOrder, double[] out, long[] pivots, int[] perm);
 
+  /** lpx_solve_multi — LPSolver.solve with the row blocks of the tableau on the GPUs `devices[0..ndev)` of this node
+   *  (one handle, peer-to-peer exchange inside the decision kernels; phase 1 included).  Outputs as solve. */
+  static native int solveMulti(int m, int n, double[] a, double[] b, double[] c, boolean maximize,
+                               int[] restoreOrder, int[] devices, int ndev, double[] out, long[] pivots, int[] perm);
+
   /** lpx_state_create — replaces new LPState(A, b, c, v, variables, coefficients, m, n) (LPState.java:101). */
   static native long stateCreate(int m, int n, double[] a, double[] b, double[] c, double v, int[] perm);
 

@@ -25,6 +25,7 @@ JNIEXPORT jint JNICALL NAME(solve)(JNIEnv* env, jclass cls, jint m, jint n, jdou
   opts.device = 0;
   opts.max_pivots = -1;
   opts.restore_order = (const int32_t*)order;
+  opts.restore_order_len = jorder ? (int32_t)(*env)->GetArrayLength(env, jorder) : 0;
   opts.perm_out = (int32_t*)perm;
   lpx_solve_result res;
   int status = lpx_solve(m, n, a, n, b, c, maximize ? 1 : 0, &opts, &res);
@@ -38,6 +39,38 @@ JNIEXPORT jint JNICALL NAME(solve)(JNIEnv* env, jclass cls, jint m, jint n, jdou
   }
   put_d(env, ja, a, JNI_ABORT); put_d(env, jb, b, JNI_ABORT); put_d(env, jc, c, JNI_ABORT);
   put_i(env, jorder, order, JNI_ABORT);
+  put_i(env, jperm, perm, 0);
+  return status;
+}
+
+/* lpx_solve_multi: LPSolver.solve with the row blocks of the tableau on several GPUs of the node (devices[] = HIP
+ * ordinals).  Same outputs as solve. */
+JNIEXPORT jint JNICALL NAME(solveMulti)(JNIEnv* env, jclass cls, jint m, jint n, jdoubleArray ja, jdoubleArray jb,
+                                        jdoubleArray jc, jboolean maximize, jintArray jorder, jintArray jdevices,
+                                        jint ndev, jdoubleArray jout, jlongArray jpivots, jintArray jperm) {
+  (void)cls;
+  double *a = get_d(env, ja), *b = get_d(env, jb), *c = get_d(env, jc);
+  jint* order = get_i(env, jorder);
+  jint* devices = get_i(env, jdevices);
+  jint* perm = get_i(env, jperm);
+  lpx_solve_options opts = {0};
+  opts.max_pivots = -1;
+  opts.restore_order = (const int32_t*)order;
+  opts.restore_order_len = jorder ? (int32_t)(*env)->GetArrayLength(env, jorder) : 0;
+  opts.perm_out = (int32_t*)perm;
+  lpx_solve_result res;
+  int status = lpx_solve_multi(m, n, a, n, b, c, maximize ? 1 : 0, &opts, (const int32_t*)devices, ndev, &res);
+  if (jout) {
+    jdouble o[2] = {res.objective, res.objective_rounded};
+    (*env)->SetDoubleArrayRegion(env, jout, 0, 2, o);
+  }
+  if (jpivots) {
+    jlong p[2] = {res.pivots_phase1, res.pivots_phase2};
+    (*env)->SetLongArrayRegion(env, jpivots, 0, 2, p);
+  }
+  put_d(env, ja, a, JNI_ABORT); put_d(env, jb, b, JNI_ABORT); put_d(env, jc, c, JNI_ABORT);
+  put_i(env, jorder, order, JNI_ABORT);
+  put_i(env, jdevices, devices, JNI_ABORT);
   put_i(env, jperm, perm, 0);
   return status;
 }

@@ -37,5 +37,6 @@ struct JNINativeInterface_ {
   void (*SetLongArrayRegion)(JNIEnv* env, jlongArray array, jsize start, jsize len, const jlong* buf);
   void (*GetLongArrayRegion)(JNIEnv* env, jlongArray array, jsize start, jsize len, jlong* buf);
   jstring (*NewStringUTF)(JNIEnv* env, const char* utf);
+  jsize (*GetArrayLength)(JNIEnv* env, jarray array);
 };
 #endif

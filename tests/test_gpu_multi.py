@@ -233,3 +233,32 @@ def test_multi_cfg4_shape_two_blocks_vs_oracle(lps, oracle):
     assert np.array_equal(bits(gb), bits(wb)) and np.array_equal(bits(gc), bits(wc))
     assert mt.checksum() == checksum_host(wA, wb, wc)
     mt.close()
+
+
+def test_c_host_without_python_in_the_compute_path(tmp_path):
+    """The boundary is a C ABI: a plain C program (tests/c_host/solve_from_c.c) links liblpx.so and solves the Spock
+    LPs and a dense LP on one device and through lpx_solve_multi / lpx_multi_* — no Python, no torch in that process.
+    One-device and multi-device results must agree bit for bit, the reference's answers and messages must come out,
+    and an exactly sized perm_out must not be overrun."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "linear_programming_solver_amd")
+    exe = tmp_path / "solve_from_c"
+    cc = shutil.which("gcc") or shutil.which("cc")
+    subprocess.check_call([cc, "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_host", "solve_from_c.c"), "-L", libdir, "-llpx",
+                           "-Wl,-rpath," + libdir, "-o", str(exe)])
+    env = dict(os.environ, LPX_HOST_DEVICES="0,0,0", GPU_MAX_HW_QUEUES="16")
+    out = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = {" ".join(ln.split()[:2]): ln for ln in out.stdout.splitlines() if ln}
+    assert "text 8.000000" in lines["spec8 one"] and "status 0" in lines["spec8 one"]
+    assert "text 20.000000" in lines["phase1 one"] and "p1 3 p2 2 x0 1" in lines["phase1 one"]
+    assert 'status 2' in lines["infeasible one"] and '"This linear program is infeasible"' in lines["infeasible one"]
+    for name in ("spec8", "phase1", "infeasible"):
+        assert lines[name + " one"].split(" ", 2)[2] == lines[name + " multi"].split(" ", 2)[2], name
+    assert lines["guard 12345"].split() == ["guard", "12345", "12345"]
+    dense = [ln for ln in out.stdout.splitlines() if ln.startswith("dense rc")]
+    assert len(dense) == 2 and dense[0].startswith("dense rc 0 one 150/9") and dense[1].startswith("dense rc 0 multi 150/9")
+    assert dense[0].split()[5:] == dense[1].split()[5:], dense     # checksums of A, b, c and the bits of v
