@@ -1610,10 +1610,16 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
                                                       const double* __restrict__ prow_ring,
                                                       const double* __restrict__ col_ring, int64_t mp,
                                                       const LpxCtl* __restrict__ ring, int kmax,
-                                                      int rows_per_wg, int nstrips, unsigned* census) {
+                                                      int rows_per_wg, int nstrips, unsigned* census, int complement) {
   __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
   constexpr int CH = kSweepChunk;
+  if (complement) {
+    // k_sweep32_steady has taken the full strips of a full block: only what it leaves is done here
+    const int np0 = ring_count(ring, K, kmax, &sh_np);
+    if (np0 == K && (blockIdx.x % nstrips + 1) * 512 <= (int)ld) return;
+    __syncthreads();
+  }
   // rows per batch (register budget: 2K doubles of pivot rows); K = 32 with 8 rows measured 13 % slower (r02)
 #ifndef LPX_STRIP_RB
 #define LPX_STRIP_RB 4
@@ -1767,6 +1773,135 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
     o[0] = wg_t0; o[1] = wall_clock64();
   }
 #endif
+}
+
+// ---- the steady state of the sweep: a full block of 32 pivots over full 512-column strips --------------------------
+// Same work split and arithmetic as k_update_multi<32>, but the tableau loads are issued by hand so that TWO batches
+// per wave are in flight.  Why: the compiler sinks a software prefetch below the arithmetic that separates it from
+// its first use (and follows a volatile load with s_waitcnt vmcnt(0)), which leaves one batch in flight however many
+// buffers the source names — and the timestamps say a batch's loads come back after ~3 us while its arithmetic takes
+// 1-2 us (profiles/r02_sweep_wg_lifetimes.txt).  asm volatile keeps the loads where they are written; the matching
+// wait names the destination registers as in/out operands so that nothing reads them earlier.  vmcnt counts in issue
+// order: "at most N outstanding" completes every operation that has at least N younger ones, so operations the
+// compiler adds in between (its stores, the odd spill) only lengthen a wait; a wait can only be too short if FEWER
+// operations follow than assumed — hence vmcnt(0) for the last batches of a run, and the first two batches of a run
+// come from ordinary loads the compiler waits for by itself.  Everything that is not a full strip of a full block
+// (np < 32, the partial last strip) is left to k_update_multi<32>(complement = 1), launched right behind.
+__device__ __forceinline__ void strip_load16(d2& x, const char* base, uint32_t off, bool nt) {
+  if (nt) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(x) : "v"(off), "s"(base) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(x) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void strip_load8(double& x, const char* base, uint32_t off) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(x) : "v"(off), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void strip_wait4(d2 (&x)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N) : "memory");
+}
+
+template <bool NT, bool OOP>
+__global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                           int64_t ld, int m_local,
+                                                           const double* __restrict__ prow_ring,
+                                                           const double* __restrict__ col_ring, int64_t mp,
+                                                           const LpxCtl* __restrict__ ring, int kmax, int rows_per_wg,
+                                                           int nstrips_full) {
+  constexpr int K = 32, RB = 4, NB = 3, CH = 48, PF = K * CH / 256;   // 12 batches per chunk, 6 parked multipliers
+  static_assert((CH / RB) % NB == 0 && 2 * CH <= kSweepMaxRows && K * CH % 256 == 0, "chunk geometry");
+  __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
+  __shared__ int sh_np;
+  if (ring_count(ring, K, kmax, &sh_np) != K) return;   // a partly filled block: k_update_multi takes all of it
+  const int strip = blockIdx.x % nstrips_full;
+  const int grp = blockIdx.x / nstrips_full;
+  const int cj = strip * 512 + 2 * threadIdx.x;
+  const int r_begin = grp * rows_per_wg;
+  const int nrows = min(m_local, r_begin + rows_per_wg) - r_begin;   // a multiple of RB (the launcher checks m_local)
+  if (nrows <= 0) return;
+  char* const tile_base = reinterpret_cast<char*>(A + (int64_t)r_begin * ld + strip * 512);
+  const char* const src_base =
+      OOP ? reinterpret_cast<const char*>(Asrc + (int64_t)r_begin * ld + strip * 512) : tile_base;
+  const char* const col_base = reinterpret_cast<const char*>(col_ring + r_begin);
+  const uint32_t row_bytes = (uint32_t)ld * 8u;   // rows_per_wg * ld * 8 < 2^32 (launcher)
+  const uint32_t off0 = threadIdx.x * 16u;
+  const int full = nrows / RB;
+
+  // prologue with ordinary loads: chunk 0's multipliers, the thread's 32 pivot-row slices, batches 0 and 1
+  for (int idx = threadIdx.x; idx < K * CH; idx += 256) {
+    const int sidx = idx / CH, r = idx % CH;
+    sh_col[sidx][r] = (r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;
+  }
+  d2 pr[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj);
+  d2 xb[NB][RB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u)
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      xb[u][r] = d2{0.0, 0.0};
+      if (u + 1 < NB && u < full) {  // uniform
+        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(u * RB + r) * row_bytes));
+        xb[u][r] = NT ? __builtin_nontemporal_load(q) : *q;
+      }
+    }
+  __syncthreads();
+
+  const int nchunks = (nrows + CH - 1) / CH;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int half = (ch & 1) * CH;
+    const bool more = ch + 1 < nchunks;   // then this chunk is a full one: 12 batches, 96 memory operations
+    double colpf[PF];
+    if (more) {   // the next chunk's multipliers: requested now (by hand, like the rows), parked, published at the end
+      const int n_next = min(CH, nrows - (ch + 1) * CH);
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        const int sidx = idx / CH, r = idx % CH;
+        colpf[k] = 0.0;
+        if (r < n_next)
+          strip_load8(colpf[k], col_base, (uint32_t)(((int64_t)sidx * mp + (ch + 1) * CH + r) * 8));
+      }
+    }
+    const int b_lo = ch * (CH / RB), b_hi = min(full, b_lo + CH / RB);
+#pragma unroll 1
+    for (int bt = b_lo; bt < b_hi; bt += NB) {   // b_lo is a multiple of NB: buffer u holds batch bt + u
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        if (bt + u < b_hi) {  // uniform
+          const int r0 = (bt + u) * RB;
+          const bool ahead = bt + u + NB - 1 < full;   // uniform
+          if (ahead) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+              strip_load16(xb[(u + NB - 1) % NB][r], src_base, off0 + (uint32_t)(r0 + (NB - 1) * RB + r) * row_bytes, NT);
+          }
+          if (bt + u >= NB - 1) {
+            // younger than this batch's loads: RB stores and RB loads per batch in between, NB - 1 batches
+            if (ahead) strip_wait4<2 * RB * (NB - 1)>(xb[u]);
+            else strip_wait4<0>(xb[u]);   // the tail of the run: fewer operations follow
+          }
+          sweep_apply<K, RB, kSweepAll>(xb[u], pr, sh_col, K, half + r0 % CH);
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+            if (NT) __builtin_nontemporal_store(xb[u][r], q); else *q = xb[u][r];
+          }
+        }
+      }
+    }
+    if (more) {
+      // 96 memory operations were issued after the multiplier requests: they are long back (vmcnt is 6 bits wide)
+      asm volatile("s_waitcnt vmcnt(32)"
+                   : "+v"(colpf[0]), "+v"(colpf[1]), "+v"(colpf[2]), "+v"(colpf[3]), "+v"(colpf[4]), "+v"(colpf[5])
+                   :: "memory");
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        sh_col[idx / CH][(CH - half) + idx % CH] = colpf[k];
+      }
+      __syncthreads();
+    }
+  }
 }
 
 // One pivot applied to one value with the reference's full case analysis (LPState.java:139-164): the value at
@@ -2123,16 +2258,30 @@ static void launch_sweep_tiles(const Buffers& B, const BlockRing& R, int m_local
 
 template <int K>
 static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
-                           const double* A_src, hipStream_t s) {
+                           const double* A_src, hipStream_t s, int complement = 0) {
   const int nstrips = (int)((B.ld + 511) / 512);
   const int ngroups = (m_local + rows_per_wg - 1) / rows_per_wg;
   const dim3 grid(nstrips * ngroups), block(256);
 #define LPX_LAUNCH_SWEEP(NT_, OOP_)                                                                              \
   hipLaunchKernelGGL((k_update_multi<K, NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, \
-                     R.mp, R.up, kmax, rows_per_wg, nstrips, R.census ? R.census + kChainMaxWgs : nullptr)
+                     R.mp, R.up, kmax, rows_per_wg, nstrips, R.census ? R.census + kChainMaxWgs : nullptr, complement)
   if (A_src) { if (nt) LPX_LAUNCH_SWEEP(true, true); else LPX_LAUNCH_SWEEP(false, true); }
   else { if (nt) LPX_LAUNCH_SWEEP(true, false); else LPX_LAUNCH_SWEEP(false, false); }
 #undef LPX_LAUNCH_SWEEP
+}
+
+// the steady-state kernel over the full strips (a no-op unless all 32 pivots of the block are valid)
+static void launch_sweep_steady(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
+                                const double* A_src, hipStream_t s) {
+  const int nstrips_full = (int)(B.ld / 512);
+  const int ngroups = (m_local + rows_per_wg - 1) / rows_per_wg;
+  const dim3 grid(nstrips_full * ngroups), block(256);
+#define LPX_LAUNCH_STEADY(NT_, OOP_)                                                                                \
+  hipLaunchKernelGGL((k_sweep32_steady<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
+                     R.up, kmax, rows_per_wg, nstrips_full)
+  if (A_src) { if (nt) LPX_LAUNCH_STEADY(true, true); else LPX_LAUNCH_STEADY(false, true); }
+  else { if (nt) LPX_LAUNCH_STEADY(true, false); else LPX_LAUNCH_STEADY(false, false); }
+#undef LPX_LAUNCH_STEADY
 }
 
 // Rows per workgroup of the sweep (a multiple of its 64-row chunk).  A workgroup pays its prologue (the 2K doubles of
@@ -2195,7 +2344,16 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     if (rows_per_wg <= 0) rows_per_wg = choose_sweep_rows(m_local, B.ld, K, cus);
     rows_per_wg = std::max(kSweepChunk, (rows_per_wg + kSweepChunk - 1) / kSweepChunk * kSweepChunk);
     while (rows_per_wg > kSweepChunk && (int64_t)rows_per_wg * B.ld * 8 >= (int64_t)1 << 32) rows_per_wg -= kSweepChunk;  // 32-bit offsets
-    launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s);
+#ifndef LPX_NO_STEADY_SWEEP
+    if (m_local % 4 == 0 && B.ld >= 512) {
+      // full block over the full strips: hand-pipelined kernel (48-row chunks); the rest — a block that ends early,
+      // the partial last strip — by the generic kernel, which skips what the first one took
+      const int rows48 = std::max(48, rows_per_wg / 48 * 48);
+      launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
+      launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);
+    } else
+#endif
+      launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s);
   }
   if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
