@@ -16,5 +16,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1; echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1; echo "write rc=$?"
 cd $R
-python scripts/pmc_traffic.py $OUT/fetch/*/*_counter_collection.csv $OUT/write/*/*_counter_collection.csv k_update_multi 32768 16384 cfg4 32 > gpurun_out/m_traffic_cfg4_n1.json; cat gpurun_out/m_traffic_cfg4_n1.json | tail -8
+python scripts/pmc_traffic.py $OUT/fetch/*/*_counter_collection.csv $OUT/write/*/*_counter_collection.csv k_sweep32_steady 32768 16384 cfg4 32 > gpurun_out/m_traffic_cfg4_n1.json; cat gpurun_out/m_traffic_cfg4_n1.json | tail -8
 cat $OUT/stats/*/*_kernel_stats.csv | cut -c1-160
