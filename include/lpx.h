@@ -120,7 +120,7 @@ int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving);
  * only supply the initial values (debugging aid for the scripts/ helpers).  Setting an option between two loops
  * is allowed; inside a loop nothing reads them.  Unknown key / value out of range -> LPX_BAD_ARGUMENT. */
 typedef enum lpx_option {
-  LPX_OPT_BLOCK = 0,          /* pivots per sweep: 0 = by size, 1 = off, 2..32 (same as lpx_state_set_block)        */
+  LPX_OPT_BLOCK = 0,          /* pivots per sweep: 0 = by size, 1 = off, 2..64 (same as lpx_state_set_block)        */
   LPX_OPT_CHAIN = 1,          /* 1 = all decisions of a block in one persistent launch (default); 0 = three launches */
   LPX_OPT_OVERLAP = 2,        /* 1 = decisions of block k+1 beside the sweep of block k (default); 0 = serial        */
   LPX_OPT_OVERLAP_SERIAL = 3, /* 1 = the overlapped loop's kernels and buffers without concurrency (diagnostics)     */
@@ -165,7 +165,9 @@ int lpx_state_read_chain_trace(lpx_state* s, int64_t* ticks, int32_t cap, int32_
  * taken from the not-yet-updated tableau (each needs one column and one row, recovered by the pending pivots'
  * rank-1 formulas) and then applied in ONE sweep that runs every entry through the K updates in order —
  * bit-identical to K separate updates, 1/K of the HBM traffic per pivot.  0 = choose by size (default),
- * 1 = off (one update pass per pivot), 2..32 = fixed (powers of two sweep fastest).  On an unsharded handle the
+ * 1 = off (one update pass per pivot), 2..64 = fixed (powers of two sweep fastest; the by-size choice stops at 32:
+ * blocks of 33..64 use a two-stage sweep and 64-slot decisions, worth +3..5 % only on tableaux of 4 GiB and more;
+ * shards and lpx_multi handles, and the loop with LPX_OPT_CHAIN = 0, use at most 32).  On an unsharded handle the
  * K decisions are one persistent launch and run beside the previous block's sweep, which then works out of place:
  * the handle allocates a second tableau (same size) at the first blocked loop. */
 int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep);

@@ -538,7 +538,12 @@ int choose_block(const lpx_state* s) {
     if (sweep_us < 15.0) K = 1;        // cache-resident tableaux: the two-launch loop wins
     else if (sweep_us < 250.0) K = 16;
     else K = 32;
+    // 64 (opt-in): the two-stage sweep moves half the bytes per pivot and takes 0.74x the time per pivot alone on the
+    // chip, but 64-slot decisions cost twice as much each (their ring reads grow with K^2) and take bandwidth from the
+    // sweep beside them: +3..5 % over 32 from 4 GiB to 12 GiB tableaux (profiles/r02_block64_policy.txt), -22 % at 2 GiB
   }
+  // three launches per decision (option chain = 0, the form the shards use): its kernels hold at most 32 pending pivots
+  if (!s->opt[LPX_OPT_CHAIN] || s->m_global != s->m) K = std::min(K, (int)lpxk::kShardBlockMax);
   return std::max(1, std::min(K, (int)lpxk::kBlockMax));
 }
 
@@ -822,7 +827,7 @@ extern "C" int lpx_state_get_block(const lpx_state* s) { return s ? choose_block
 
 // ---- blocked pivoting on row-block shards: the host exchanges the candidate of every decision ---------------
 extern "C" int lpx_shard_block_peek(lpx_state* s, double* d_candidate, int32_t slot) {
-  if (!s || !d_candidate || slot < 0 || slot >= lpxk::kBlockMax)
+  if (!s || !d_candidate || slot < 0 || slot >= lpxk::kShardBlockMax)
     return fail(LPX_BAD_ARGUMENT, "lpx_shard_block_peek: bad argument");
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = ensure_block_ring(s)) return rc;
@@ -832,7 +837,7 @@ extern "C" int lpx_shard_block_peek(lpx_state* s, double* d_candidate, int32_t s
 }
 
 extern "C" int lpx_shard_block_decide(lpx_state* s, const double* d_gathered, int32_t nranks, int32_t slot) {
-  if (!s || !d_gathered || nranks < 1 || slot < 0 || slot >= lpxk::kBlockMax)
+  if (!s || !d_gathered || nranks < 1 || slot < 0 || slot >= lpxk::kShardBlockMax)
     return fail(LPX_BAD_ARGUMENT, "lpx_shard_block_decide: bad argument");
   HIP_TRY(hipSetDevice(s->device));
   if (int rc = ensure_block_ring(s)) return rc;
@@ -843,7 +848,7 @@ extern "C" int lpx_shard_block_decide(lpx_state* s, const double* d_gathered, in
 }
 
 extern "C" int lpx_shard_block_sweep(lpx_state* s, int32_t nslots) {
-  if (!s || nslots < 0 || nslots > lpxk::kBlockMax) return fail(LPX_BAD_ARGUMENT, "lpx_shard_block_sweep: bad argument");
+  if (!s || nslots < 0 || nslots > lpxk::kShardBlockMax) return fail(LPX_BAD_ARGUMENT, "lpx_shard_block_sweep: bad argument");
   HIP_TRY(hipSetDevice(s->device));
   if (nslots == 0) return 0;
   if (int rc = ensure_block_ring(s)) return rc;
@@ -852,7 +857,7 @@ extern "C" int lpx_shard_block_sweep(lpx_state* s, int32_t nslots) {
 
 extern "C" int lpx_state_set_block(lpx_state* s, int32_t pivots_per_sweep) {
   if (!s || pivots_per_sweep < 0 || pivots_per_sweep > lpxk::kBlockMax)
-    return fail(LPX_BAD_ARGUMENT, "lpx_state_set_block: 0 (auto), 1 (off) .. 32");
+    return fail(LPX_BAD_ARGUMENT, "lpx_state_set_block: 0 (auto), 1 (off) .. 64");
   s->opt[LPX_OPT_BLOCK] = pivots_per_sweep;
   return 0;
 }

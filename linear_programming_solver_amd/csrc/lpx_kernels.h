@@ -80,7 +80,8 @@ void launch_commit(const Buffers& B, int n, int m_global, const double* d_gather
 void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* prow_t, const double* col_t,
                  double* col_next, const LpxCtl* pend, double* d_candidate, hipStream_t s);
 // blocked pivoting: ring of pending pivots (see lpx_kernels.hip "blocked pivoting")
-constexpr int kBlockMax = 32;
+constexpr int kBlockMax = 64;        // pivots per block / slots per ring half (single-device loop)
+constexpr int kShardBlockMax = 32;   // the step-wise shard interface and lpx_multi decide at most this many per block
 struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per block in flight
   double* prow;   // kBlockMax x ld : normalised pivot row of pending pivot s
   double* col;    // kBlockMax x mp : column e_s of the tableau just before pivot s

@@ -956,10 +956,26 @@ struct ChainArgs {
   unsigned long long* arrive_peer[kMaxDevices];  // every shard's arrival words [kChainMaxWgs]
 };
 
-template <bool MG>
+// KB: capacity of one ring half seen by the launch (32, or 64 for blocks of more than 32 pivots — the same code with
+// longer register arrays; its decisions cost more, so the launcher picks it only when a block needs it).
+// LDS layout of the per-pivot parameters: [0, KB) old half, [KB, 2 KB) own half.
+template <int KB>
+__device__ __forceinline__ int chain_restart(const unsigned long long* sh_mask) {
+  // highest LDS index whose pending pivot touched the same slot / row (ballots of the first 2 KB / 64 waves)
+  if constexpr (KB > 32) {
+    const unsigned long long hi = sh_mask[1], lo = sh_mask[0];
+    return hi ? 127 - __clzll((long long)hi) : (lo ? 63 - __clzll((long long)lo) : -1);
+  } else {
+    const unsigned long long lo = sh_mask[0];
+    return lo ? 63 - __clzll((long long)lo) : -1;
+  }
+}
+
+template <bool MG, int KB>
 __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
-  constexpr int KB = kMaxBlock;  // LDS layout of the per-pivot parameters: [0, KB) old half, [KB, 2 KB) own half
+  static_assert(KB == 32 || KB == 64, "ring half of 32 or 64 slots");
   __shared__ RatioRow sh_rr[4];
+  __shared__ unsigned long long sh_mask[2];
   __shared__ double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB], sh_win[2];
   __shared__ int sh_e[2 * KB], sh_l[2 * KB];
   __shared__ int sh_fail, sh_restart;
@@ -1002,21 +1018,21 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     // b needs no chain at all: own_b holds it with every decided pivot applied (one step added per decision).
     if (P.dbg && lead) P.dbg[s * 5 + 0] = wall_clock64();
     const double pc = ld_agent(&P.c[e]);  // c[e] is rewritten only in phase B, after the next barrier
-    if (tid < 64) {
+    if (tid < 2 * KB) {
       const int r = tid & (KB - 1);
       const bool old = tid < KB;
       const bool valid = old ? r < n_old : r < s;
       bool same = false;
-      if (valid) {  // one wave per workgroup fetches prow_u[e] of every pending pivot u
+      if (valid) {  // one lane per pending pivot u fetches prow_u[e]
         const double* pe_src = (old ? P.prow_o : P.prow) + (int64_t)r * ld + e;
         sh_pe[tid] = MG ? ld_sys(pe_src) : ld_agent(pe_src);  // on a shard: possibly stored by a peer device
         same = sh_e[tid] == e;
       }
       const unsigned long long mask = __ballot(same);
-      if (tid == 0) sh_restart = mask ? 63 - __clzll((long long)mask) : -1;
+      if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
     }
     __syncthreads();
-    const int ra = sh_restart;                                   // LDS index of the restart pivot, -1: none
+    const int ra = chain_restart<KB>(sh_mask);                   // LDS index of the restart pivot, -1: none
     const int fo_a = ra < 0 ? 0 : (ra < KB ? ra + 1 : n_old);    // first live step of the old half
     const int fn_a = ra >= KB ? ra - KB + 1 : 0;                 // first live step of this block's half
     const bool use_b = P.b_from_tableau && s == 0;
@@ -1167,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     // On shards only the device that holds row l computes it; the others receive the normalised row (see below).
     const bool owner = !MG || (l >= row0 && l < row0 + m);
     const int ll = l - row0;  // local index of the leaving row on its owner
-    if (tid < 64) {
+    if (tid < 2 * KB) {
       const int r = tid & (KB - 1);
       const bool old = tid < KB;
       const bool valid = owner && (old ? r < n_old : r < s);
@@ -1179,10 +1195,10 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         same = sh_l[tid] == l;
       }
       const unsigned long long mask = __ballot(same);
-      if (tid == 0) sh_restart = mask ? 63 - __clzll((long long)mask) : -1;
+      if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
     }
     __syncthreads();
-    const int rb = sh_restart;
+    const int rb = chain_restart<KB>(sh_mask);
     const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
     const int fn_b = rb >= KB ? rb - KB + 1 : 0;
     const double bl = __ddiv_rn(raw_b, p);                                         // :146
@@ -1610,16 +1626,22 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
                                                       const double* __restrict__ prow_ring,
                                                       const double* __restrict__ col_ring, int64_t mp,
                                                       const LpxCtl* __restrict__ ring, int kmax,
-                                                      int rows_per_wg, int nstrips, unsigned* census, int complement) {
+                                                      int rows_per_wg, int nstrips, unsigned* census, int complement,
+                                                      int slot0) {
+  // slot0: this pass applies the pending pivots slot0 .. slot0 + K - 1 of the block (a block of more than 32 goes in
+  // two passes where the one-pass kernel does not apply); the rings are passed at slot 0, kmax counts from slot 0.
+  // complement (0, or the block length the steady-state kernel needs): that kernel has taken the full strips of a
+  // full block, only what it leaves is done here.
   __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
   constexpr int CH = kSweepChunk;
   if (complement) {
-    // k_sweep32_steady has taken the full strips of a full block: only what it leaves is done here
-    const int np0 = ring_count(ring, K, kmax, &sh_np);
-    if (np0 == K && (blockIdx.x % nstrips + 1) * 512 <= (int)ld) return;
+    const int np0 = ring_count(ring, kBlockMax, kmax, &sh_np);
+    if (np0 == complement && (blockIdx.x % nstrips + 1) * 512 <= (int)ld) return;
     __syncthreads();
   }
+  prow_ring += (int64_t)slot0 * ld;
+  col_ring += (int64_t)slot0 * mp;
   // rows per batch (register budget: 2K doubles of pivot rows); K = 32 with 8 rows measured 13 % slower (r02)
 #ifndef LPX_STRIP_RB
 #define LPX_STRIP_RB 4
@@ -1648,7 +1670,7 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
   // Prologue, once per workgroup: the ring's flags, the first chunk's multipliers, the thread's slices of the K pivot
   // rows and the first batch of rows are requested together — ONE memory round trip, not four.
   bool ok = false;
-  if (threadIdx.x < 64) ok = (int)threadIdx.x < K && (int)threadIdx.x < kmax && ring[threadIdx.x].do_update != 0;
+  if (threadIdx.x < 64) ok = (int)threadIdx.x < kmax && ring[threadIdx.x].do_update != 0;   // kmax <= 64 slots
   for (int idx = threadIdx.x; idx < K * CH; idx += 256) {
     const int sidx = idx / CH, r = idx % CH;
     sh_col[sidx][r] = (r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;  // slots >= np: never used
@@ -1674,7 +1696,10 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
   }
   if (threadIdx.x < 64) {
     const unsigned long long mask = __ballot(ok);
-    if (threadIdx.x == 0) sh_np = (~mask == 0ull) ? 64 : (__ffsll((long long)~mask) - 1);
+    if (threadIdx.x == 0) {
+      const int np_block = (~mask == 0ull) ? 64 : (__ffsll((long long)~mask) - 1);   // leading valid slots of the block
+      sh_np = max(0, min(K, np_block - slot0));
+    }
   }
   __syncthreads();  // chunk 0's multipliers and sh_np complete
   const int np = sh_np;
@@ -1904,6 +1929,148 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ 
   }
 }
 
+// ---- 64 pivots per pass: two stages of 32 inside one workgroup ------------------------------------------------------
+// At K = 32 the sweep is bound by memory (16 m n bytes per pass at ~5 TB/s), not by the 2 m n K unfused fp64
+// operations; twice the pivots per pass halves the bytes per pivot.  A thread cannot hold 64 pivot-row slices (256
+// registers), so the workgroup is a two-stage pipeline over the same 512-column strip: waves 0-3 hold the slices of
+// pivots 0..31, load a batch of RB rows from the tableau (by hand, two batches ahead, as k_sweep32_steady), apply their
+// 32 steps and hand the batch over in LDS; waves 4-7 hold the slices of pivots 32..63, take the batch handed over in
+// the previous round, apply their 32 steps and store it.  Lane t of wave w + 4 reads exactly what lane t of wave w
+// wrote; one workgroup barrier per round separates the two hand-over slots.  The arithmetic per entry is the same
+// 64 sequential steps in the same order as two passes of 32.
+template <bool NT, bool OOP>
+__global__ __launch_bounds__(512) void k_sweep64_pipe(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                      int64_t ld, int m_local,
+                                                      const double* __restrict__ prow_ring,
+                                                      const double* __restrict__ col_ring, int64_t mp,
+                                                      const LpxCtl* __restrict__ ring, int kmax, int rows_per_wg,
+                                                      int nstrips_full) {
+  constexpr int K = 64, KS = 32, RB = 4, NB = 3, CH = 48, PF = K * CH / 512;   // 12 rounds per chunk, 6 parked multipliers
+  static_assert((CH / RB) % NB == 0 && 2 * CH <= kSweepMaxRows && K * CH % 512 == 0 && PF == 6, "chunk geometry");
+  __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
+  __shared__ __attribute__((aligned(16))) d2 sh_x[2][RB][256];
+  __shared__ int sh_np;
+  if (ring_count(ring, K, kmax, &sh_np) != K) return;   // a partly filled block: the generic kernels take all of it
+  const int stage = threadIdx.x >> 8, t = threadIdx.x & 255;   // wave-uniform stage
+  const int strip = blockIdx.x % nstrips_full;
+  const int grp = blockIdx.x / nstrips_full;
+  const int cj = strip * 512 + 2 * t;
+  const int r_begin = grp * rows_per_wg;
+  const int nrows = min(m_local, r_begin + rows_per_wg) - r_begin;   // a multiple of RB (the launcher checks m_local)
+  if (nrows <= 0) return;
+  char* const tile_base = reinterpret_cast<char*>(A + (int64_t)r_begin * ld + strip * 512);
+  const char* const src_base =
+      OOP ? reinterpret_cast<const char*>(Asrc + (int64_t)r_begin * ld + strip * 512) : tile_base;
+  const char* const col_base = reinterpret_cast<const char*>(col_ring + r_begin);
+  const uint32_t row_bytes = (uint32_t)ld * 8u;   // rows_per_wg * ld * 8 < 2^32 (launcher)
+  const uint32_t off0 = t * 16u;
+  const int full = nrows / RB;
+
+  for (int idx = threadIdx.x; idx < K * CH; idx += 512) {
+    const int sidx = idx / CH, r = idx % CH;
+    sh_col[sidx][r] = (r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;
+  }
+  d2 pr[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)(stage * KS + s) * ld + cj);
+  d2 xb[NB][RB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u)
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      xb[u][r] = d2{0.0, 0.0};
+      if (stage == 0 && u + 1 < NB && u < full) {  // uniform
+        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(u * RB + r) * row_bytes));
+        xb[u][r] = NT ? __builtin_nontemporal_load(q) : *q;
+      }
+    }
+  __syncthreads();
+  const double (*const my_col)[kSweepMaxRows] = sh_col + stage * KS;
+
+  const int nchunks = (nrows + CH - 1) / CH;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int half = (ch & 1) * CH;
+    const bool more = ch + 1 < nchunks;   // then this chunk is a full one
+    double colpf[PF];
+    if (more) {
+      const int n_next = min(CH, nrows - (ch + 1) * CH);
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int idx = threadIdx.x + k * 512;
+        const int sidx = idx / CH, r = idx % CH;
+        colpf[k] = 0.0;
+        if (r < n_next)
+          strip_load8(colpf[k], col_base, (uint32_t)(((int64_t)sidx * mp + (ch + 1) * CH + r) * 8));
+      }
+    }
+    const int b_lo = ch * (CH / RB), b_hi = min(full, b_lo + CH / RB);
+#pragma unroll 1
+    for (int bt = b_lo; bt < b_hi; bt += NB) {   // b_lo is a multiple of NB: buffer u holds batch bt + u
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int it = bt + u;   // round `it`: stage 0 works on batch it, stage 1 on batch it - 1
+        if (it < b_hi) {  // uniform
+          if (stage == 0) {
+            const int r0 = it * RB;
+            const bool ahead = it + NB - 1 < full;   // uniform
+            if (ahead) {
+#pragma unroll
+              for (int r = 0; r < RB; ++r)
+                strip_load16(xb[(u + NB - 1) % NB][r], src_base, off0 + (uint32_t)(r0 + (NB - 1) * RB + r) * row_bytes, NT);
+            }
+            if (it >= NB - 1) {
+              // younger than this batch's loads: the RB loads of each of the NB - 1 batches behind it (this stage
+              // stores nothing; parked multiplier requests in between only make the wait stricter)
+              if (ahead) strip_wait4<RB * (NB - 1)>(xb[u]);
+              else strip_wait4<0>(xb[u]);
+            }
+            sweep_apply<KS, RB, kSweepAll>(xb[u], pr, my_col, KS, half + r0 % CH);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) sh_x[it & 1][r][t] = xb[u][r];
+          } else if (it >= 1) {
+            const int r0 = (it - 1) * RB;
+            const int half1 = (((it - 1) / (CH / RB)) & 1) * CH;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) xb[u][r] = sh_x[(it - 1) & 1][r][t];   // (this stage's buffers are free)
+            sweep_apply<KS, RB, kSweepAll>(xb[u], pr, my_col, KS, half1 + r0 % CH);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+              d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+              if (NT) __builtin_nontemporal_store(xb[u][r], q); else *q = xb[u][r];
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+    if (more) {
+      // >= 44 memory operations were issued after the multiplier requests (48 loads by stage 0; the stores of 11 or
+      // 12 batches by stage 1): they are long back (vmcnt counts in issue order)
+      asm volatile("s_waitcnt vmcnt(32)"
+                   : "+v"(colpf[0]), "+v"(colpf[1]), "+v"(colpf[2]), "+v"(colpf[3]), "+v"(colpf[4]), "+v"(colpf[5])
+                   :: "memory");
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        const int idx = threadIdx.x + k * 512;
+        sh_col[idx / CH][(CH - half) + idx % CH] = colpf[k];
+      }
+      __syncthreads();
+    }
+  }
+  if (stage == 1 && full >= 1) {   // the last batch handed over
+    const int r0 = (full - 1) * RB;
+    const int half1 = (((full - 1) / (CH / RB)) & 1) * CH;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) xb[0][r] = sh_x[(full - 1) & 1][r][t];
+    sweep_apply<KS, RB, kSweepAll>(xb[0], pr, my_col, KS, half1 + r0 % CH);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
+      if (NT) __builtin_nontemporal_store(xb[0][r], q); else *q = xb[0][r];
+    }
+  }
+}
+
 // One pivot applied to one value with the reference's full case analysis (LPState.java:139-164): the value at
 // row i, column j before pivot r -> after pivot r.
 __device__ __forceinline__ double apply_pivot(double v, int i, int j, int l_r, int e_r, double p_r, double ce,
@@ -1922,11 +2089,11 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
                                                      const double* __restrict__ row0_ring, int64_t mp,
                                                      const LpxCtl* __restrict__ ring, int kmax,
                                                      const double* b_src) {
-  __shared__ double sh_p[kMaxBlock], sh_bl[kMaxBlock], sh_x[kMaxBlock];
-  __shared__ int sh_e[kMaxBlock], sh_l[kMaxBlock];
+  __shared__ double sh_p[kBlockMax], sh_bl[kBlockMax], sh_x[kBlockMax];
+  __shared__ int sh_e[kBlockMax], sh_l[kBlockMax];
   __shared__ int sh_np;
   const int s = blockIdx.y, job = blockIdx.z;
-  const int np = ring_count(ring, kMaxBlock, kmax, &sh_np);
+  const int np = ring_count(ring, kBlockMax, kmax, &sh_np);
   if (job == 2 ? s != 0 : s >= np) return;  // the b job also runs for an empty block (out of place: it copies b)
   if ((int)threadIdx.x < np) {
     const LpxCtl& q = ring[threadIdx.x];
@@ -2201,6 +2368,7 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   int G = wgs > 0 ? wgs : (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 511) / 512));
   G = std::max(1, std::min(G, kChainMaxWgs));
   const int64_t K = kBlockMax;
+  const bool wide = nb > 32 || n_old > 32;   // a block of more than 32 pivots on either side: the 64-slot form
   ChainArgs P{};
   P.A = B.A; P.b = B.b; P.ld = B.ld; P.mp = R.mp; P.n = n; P.m = m;
   P.c = B.c; P.perm = B.perm; P.ctl = B.ctl;
@@ -2226,20 +2394,24 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
       P.prow_peer[d] = mg->prow[d] + ho * B.ld;   // the same ring half on every shard
       P.arrive_peer[d] = mg->arrive[d];
     }
-    hipLaunchKernelGGL(k_block_chain_t<true>, dim3(G), dim3(256), 0, s, P);
+    if (wide) hipLaunchKernelGGL((k_block_chain_t<true, 64>), dim3(G), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(G), dim3(256), 0, s, P);
   } else {
     P.m_global = m; P.n_dev = 1;
-    hipLaunchKernelGGL(k_block_chain_t<false>, dim3(G), dim3(256), 0, s, P);
+    if (wide) hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(G), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL((k_block_chain_t<false, 32>), dim3(G), dim3(256), 0, s, P);
   }
 }
 
 int chain_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_block_chain_t<true>, 256, 0) != hipSuccess) {
+  int nw = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_block_chain_t<true, 32>), 256, 0) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, (k_block_chain_t<false, 64>), 256, 0) != hipSuccess) {
     (void)hipGetLastError();
-    nb = 1;
+    nb = nw = 1;
   }
-  return std::max(1, nb);
+  return std::max(1, std::min(nb, nw));
 }
 
 template <int K>
@@ -2258,13 +2430,14 @@ static void launch_sweep_tiles(const Buffers& B, const BlockRing& R, int m_local
 
 template <int K>
 static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
-                           const double* A_src, hipStream_t s, int complement = 0) {
+                           const double* A_src, hipStream_t s, int complement = 0, int slot0 = 0) {
   const int nstrips = (int)((B.ld + 511) / 512);
   const int ngroups = (m_local + rows_per_wg - 1) / rows_per_wg;
   const dim3 grid(nstrips * ngroups), block(256);
 #define LPX_LAUNCH_SWEEP(NT_, OOP_)                                                                              \
   hipLaunchKernelGGL((k_update_multi<K, NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, \
-                     R.mp, R.up, kmax, rows_per_wg, nstrips, R.census ? R.census + kChainMaxWgs : nullptr, complement)
+                     R.mp, R.up, kmax, rows_per_wg, nstrips, R.census ? R.census + kChainMaxWgs : nullptr, complement, \
+                     slot0)
   if (A_src) { if (nt) LPX_LAUNCH_SWEEP(true, true); else LPX_LAUNCH_SWEEP(false, true); }
   else { if (nt) LPX_LAUNCH_SWEEP(true, false); else LPX_LAUNCH_SWEEP(false, false); }
 #undef LPX_LAUNCH_SWEEP
@@ -2282,6 +2455,19 @@ static void launch_sweep_steady(const Buffers& B, const BlockRing& R, int m_loca
   if (A_src) { if (nt) LPX_LAUNCH_STEADY(true, true); else LPX_LAUNCH_STEADY(false, true); }
   else { if (nt) LPX_LAUNCH_STEADY(true, false); else LPX_LAUNCH_STEADY(false, false); }
 #undef LPX_LAUNCH_STEADY
+}
+
+static void launch_sweep64_pipe(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
+                                const double* A_src, hipStream_t s) {
+  const int nstrips_full = (int)(B.ld / 512);
+  const int ngroups = (m_local + rows_per_wg - 1) / rows_per_wg;
+  const dim3 grid(nstrips_full * ngroups), block(512);
+#define LPX_LAUNCH_PIPE(NT_, OOP_)                                                                                  \
+  hipLaunchKernelGGL((k_sweep64_pipe<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
+                     R.up, kmax, rows_per_wg, nstrips_full)
+  if (A_src) { if (nt) LPX_LAUNCH_PIPE(true, true); else LPX_LAUNCH_PIPE(false, true); }
+  else { if (nt) LPX_LAUNCH_PIPE(true, false); else LPX_LAUNCH_PIPE(false, false); }
+#undef LPX_LAUNCH_PIPE
 }
 
 // Rows per workgroup of the sweep (a multiple of its 64-row chunk).  A workgroup pays its prologue (the 2K doubles of
@@ -2307,6 +2493,25 @@ static int choose_sweep_rows(int m_local, int64_t ld, int K, int cus) {
   return best_rows;
 }
 
+// Rows per workgroup of the two-stage kernel: one 512-thread workgroup per CU at a time, so the grid should be a
+// whole number of rounds of `cus` workgroups (cfg4 alone on the chip: 1024 rows = 4 full rounds 2.83 ms, 672 rows =
+// 6.1 rounds 3.29 ms); three or more rounds when there is enough work, so that uneven CUs even out.
+static int choose_pipe_rows(int m_local, int nstrips_full, int cus) {
+  const int prologue_rows = 96;   // the run's pivot-row slices and first multipliers, in rows' worth of time
+  int best_rows = std::max(4, (m_local + 3) / 4 * 4);
+  int64_t best_cost = INT64_MAX;
+  for (int rounds = 1; rounds <= 8; ++rounds) {
+    const int64_t groups = std::max<int64_t>(1, (int64_t)rounds * cus / std::max(1, nstrips_full));
+    const int rows = (int)(((m_local + groups - 1) / groups + 3) / 4 * 4);
+    if (rows < 48 && rounds > 1) break;
+    const int64_t used = ((int64_t)(m_local + rows - 1) / rows * nstrips_full + cus - 1) / cus;   // rounds really needed
+    int64_t cost = used * (rows + prologue_rows);
+    if (rounds < 3) cost += cost / 16;   // no slack for uneven CUs
+    if (cost < best_cost) { best_cost = cost; best_rows = rows; }
+  }
+  return best_rows;
+}
+
 // rows_per_wg <= 0: chosen here (see choose_sweep_rows); cus: CUs the stream may use (0: the whole device)
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep,
@@ -2328,6 +2533,24 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     else if (K <= 8) launch_sweep_tiles<8>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
     else launch_sweep_tiles<16>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
     rows_per_wg = rows_per_tile;
+  } else if (K > 32) {
+    // blocks of up to 64 pivots.  A full block of 64 over the full strips goes through the two-stage kernel in one
+    // pass; whatever that leaves (a block that ended early or has fewer than 64 decisions, the partial last strip,
+    // m not a multiple of 4) takes two passes of the generic kernel: slots 0..31 (out of place when asked), then
+    // slots 32.. in place on the result.  An entry's update reads ring values only, so the split changes nothing.
+    const int nstrips_full = (int)(B.ld / 512);
+    const bool pipe = K == 64 && m_local % 4 == 0 && nstrips_full >= 1;
+    int rows64 = 0;
+    if (pipe) {
+      rows64 = rows_per_wg > 0 ? std::max(4, rows_per_wg / 4 * 4) : choose_pipe_rows(m_local, nstrips_full, cus);
+      while (rows64 > 4 && (int64_t)rows64 * B.ld * 8 >= (int64_t)1 << 32) rows64 -= 4;  // 32-bit offsets
+      launch_sweep64_pipe(B, R, m_local, K, rows64, nt, A_src, s);
+    }
+    int rows = choose_sweep_rows(m_local, B.ld, 32, cus);
+    while (rows > kSweepChunk && (int64_t)rows * B.ld * 8 >= (int64_t)1 << 32) rows -= kSweepChunk;
+    launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, pipe ? 64 : 0, 0);
+    launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, pipe ? 64 : 0, 32);
+    rows_per_wg = pipe ? rows64 : rows;
   } else if (K < kMaxBlock) {
     // a partly filled block of 17..31 pivots (the tail of a pivot budget): the tile kernel's guarded path took such
     // blocks faster than the long-run kernel's (cfg3, 20 pivots, same box: 490 vs 615 us); 64-row tiles as long as the
@@ -2350,7 +2573,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
       // the partial last strip — by the generic kernel, which skips what the first one took
       const int rows48 = std::max(48, rows_per_wg / 48 * 48);
       launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
-      launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);
+      launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 32);
     } else
 #endif
       launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s);

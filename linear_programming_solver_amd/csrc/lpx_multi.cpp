@@ -360,7 +360,7 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
     K = std::max(K, choose_block(M->sh[r]));
     work = std::max<int64_t>(work, std::max<int64_t>(M->sh[r]->m, M->sh[r]->B.ld));
   }
-  K = std::min(K, (int)lpxk::kBlockMax);
+  K = std::min(K, (int)lpxk::kShardBlockMax);
   for (int r = 0; r < G; r++) {
     lpx_state* s = M->sh[r];
     HIP_TRY(hipSetDevice(M->device[r]));

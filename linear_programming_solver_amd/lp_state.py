@@ -47,7 +47,7 @@ class LPState:
             if rc:
                 raise_for_status(rc)
 
-        if block is not None:          # pivots per sweep of the device loop: None/0 = by size, 1 = off, 2..32
+        if block is not None:          # pivots per sweep of the device loop: None/0 = by size, 1 = off, 2..64
             rc = L.lpx_state_set_block(h, int(block))
             if rc:
                 raise_for_status(rc)
@@ -174,9 +174,9 @@ class LPState:
     def chain_trace(self):
         """Phase timestamps (100 MHz ticks) of the last decision launch: array [decisions, 5]; needs option
         chain_trace = 1 before the loop."""
-        buf = np.zeros(5 * 32, dtype=np.int64)
+        buf = np.zeros(5 * 64, dtype=np.int64)
         nd = C.c_int32()
-        rc = self._L.lpx_state_read_chain_trace(self._h, buf.ctypes.data_as(_lib.i64p), 32, C.byref(nd))
+        rc = self._L.lpx_state_read_chain_trace(self._h, buf.ctypes.data_as(_lib.i64p), 64, C.byref(nd))
         if rc:
             raise_for_status(rc)
         return buf[: 5 * nd.value].reshape(nd.value, 5)

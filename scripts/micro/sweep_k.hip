@@ -1,0 +1,125 @@
+// Sweep kernels alone on a synthetic ring: K = 64 pivots in one pass against two passes of 32 (bitwise the same
+// result, since an entry's update uses ring values only).  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+//   -I linear_programming_solver_amd/csrc scripts/micro/sweep_k.hip -o scripts/micro/sweep_k
+// Run: sweep_k [m] [n] [reps]
+#include "lpx_kernels.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                                        \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } \
+  } while (0)
+
+__global__ void k_fill(double* p, int64_t n, unsigned long long seed, double scale) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    p[i] = ((double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5) * scale;
+  }
+}
+__global__ void k_diff(const double* a, const double* b, int64_t n, unsigned long long* out) {
+  unsigned long long bad = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    bad += __double_as_longlong(a[i]) != __double_as_longlong(b[i]);
+  if (bad) atomicAdd(out, bad);
+}
+
+using namespace lpxk;
+
+template <typename F>
+static float time_ms(F f, int reps) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) f();
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const int m = argc > 1 ? atoi(argv[1]) : 32768;
+  const int n = argc > 2 ? atoi(argv[2]) : 16384;
+  const int reps = argc > 3 ? atoi(argv[3]) : 10;
+  const int64_t ld = (n + 15) / 16 * 16, mp = m;
+  const int KT = 64;
+  double *src, *dst, *ref, *prow, *col;
+  LpxCtl* up;
+  unsigned long long* bad;
+  CK(hipMalloc(&src, (size_t)m * ld * 8)); CK(hipMalloc(&dst, (size_t)m * ld * 8)); CK(hipMalloc(&ref, (size_t)m * ld * 8));
+  CK(hipMalloc(&prow, (size_t)KT * ld * 8)); CK(hipMalloc(&col, (size_t)KT * mp * 8));
+  CK(hipMalloc(&up, KT * sizeof(LpxCtl))); CK(hipMalloc(&bad, 8));
+  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, src, (int64_t)m * ld, 1ull, 2.0);
+  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, prow, (int64_t)KT * ld, 2ull, 0.25);
+  hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, col, (int64_t)KT * mp, 3ull, 0.25);
+  std::vector<LpxCtl> h(KT);
+  for (int s = 0; s < KT; ++s) { h[s] = LpxCtl{}; h[s].do_update = 1; h[s].e_cur = s; h[s].l = s; h[s].p = 1.0; }
+  CK(hipMemcpy(up, h.data(), KT * sizeof(LpxCtl), hipMemcpyHostToDevice));
+  CK(hipDeviceSynchronize());
+
+  Buffers B{}; B.ld = ld;
+  BlockRing R{}; R.prow = prow; R.col = col; R.up = up; R.mp = mp;
+  BlockRing R2 = R; R2.prow = prow + 32 * ld; R2.col = col + 32 * mp; R2.up = up + 32;
+  const int cus = 256;
+  const int rows32 = std::max(48, choose_sweep_rows(m, ld, 32, cus) / 48 * 48);
+  const int rows64 = argc > 4 ? atoi(argv[4]) : std::max(48, choose_sweep_rows(m, ld, 64, cus) / 48 * 48);
+  printf("m %d n %d ld %lld rows/wg: K32 %d K64 %d\n", m, n, (long long)ld, rows32, rows64);
+
+  // reference: two passes of 32 (out of place, then in place)
+  B.A = ref;
+  auto two_pass = [&] {
+    launch_sweep_steady(B, R, m, 32, rows32, true, src, 0);
+    launch_sweep_k<32>(B, R, m, 32, rows32 / 64 * 64 > 0 ? std::max(64, rows32 / 64 * 64) : 64, true, src, 0, 1);
+    launch_sweep_steady(B, R2, m, 32, rows32, true, nullptr, 0);
+    launch_sweep_k<32>(B, R2, m, 32, std::max(64, rows32 / 64 * 64), true, nullptr, 0, 1);
+  };
+  // in-place second pass is not idempotent: time on a scratch copy, then recompute the reference once
+  const float t32 = time_ms([&] {
+    launch_sweep_steady(B, R, m, 32, rows32, true, src, 0);
+    launch_sweep_k<32>(B, R, m, 32, std::max(64, rows32 / 64 * 64), true, src, 0, 1);
+  }, reps);
+  two_pass();
+  CK(hipDeviceSynchronize());
+
+  Buffers D = B; D.A = dst;
+  const float t64 = time_ms([&] { launch_sweep64_pipe(D, R, m, 64, rows64, true, src, 0); }, reps);
+  CK(hipMemset(bad, 0, 8));
+  hipLaunchKernelGGL(k_diff, dim3(2048), dim3(256), 0, 0, dst, ref, (int64_t)m * ld, bad);
+  unsigned long long hb = 0;
+  CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
+  const double el = (double)m * ld;
+  printf("K=32 one pass  %.3f ms  (%.2f TB/s, %.1f T lane-instr/s)\n", t32, 16 * el / t32 * 1e-9, 2 * el * 32 / t32 * 1e-9);
+  printf("K=64 one pass  %.3f ms  (%.2f TB/s, %.1f T lane-instr/s)   vs 2 x K=32 = %.3f ms\n", t64, 16 * el / t64 * 1e-9,
+         2 * el * 64 / t64 * 1e-9, 2 * t32);
+  printf("mismatching entries vs two passes of 32: %llu of %.0f\n", hb, el);
+  // a few entries recomputed on the host (volatile: one rounding per operation)
+  for (int t = 0; t < 6; ++t) {
+    const int64_t i = ((int64_t)t * 7919 + 5) % m, j = ((int64_t)t * 104729 + 11) % n;
+    double x, d, r;
+    CK(hipMemcpy(&x, src + i * ld + j, 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&d, dst + i * ld + j, 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&r, ref + i * ld + j, 8, hipMemcpyDeviceToHost));
+    double x32 = 0;
+    for (int k = 0; k < KT; ++k) {
+      double c, p;
+      CK(hipMemcpy(&c, col + (int64_t)k * mp + i, 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(&p, prow + (int64_t)k * ld + j, 8, hipMemcpyDeviceToHost));
+      volatile double pr_ = c * p;
+      volatile double nx = x - pr_;
+      x = nx;
+      if (k == 31) x32 = x;
+    }
+    printf("(%lld,%lld) host64 %.17g host32 %.17g  one-pass %.17g  two-pass %.17g\n", (long long)i, (long long)j, x, x32, d, r);
+  }
+  return hb ? 2 : 0;
+}

@@ -709,7 +709,7 @@ def test_restore_index_fault_is_reported(lps, decimal_goldens):
 
 
 # ------------------------------------------------------------------------------------ blocked pivoting
-@pytest.mark.parametrize("block", [2, 3, 4, 8, 16, 21, 32])
+@pytest.mark.parametrize("block", [2, 3, 4, 8, 16, 21, 32, 33, 48, 64])
 @pytest.mark.parametrize("shape", [(50, 80), (257, 300), (200, 1100), (9, 2100)])
 def test_blocked_pivoting_is_bit_identical(lps, oracle, shape, block):
     """K pivot decisions from the stale tableau + one K-fold sweep must equal K separate updates bit for bit:
@@ -739,7 +739,7 @@ def test_blocked_pivoting_is_bit_identical(lps, oracle, shape, block):
 def test_blocked_loop_forms_are_bit_identical(lps, oracle, knobs):
     """Every form of the blocked loop (default: decisions one block ahead of out-of-place sweeps) gives the
     one-pass-per-pivot result bit for bit; the forms are selected through the handle (lpx_state_set_option)."""
-    for (m, n), block in (((300, 700), 32), ((1100, 260), 16), ((64, 2100), 8)):
+    for (m, n), block in (((300, 700), 32), ((1100, 260), 16), ((64, 2100), 8), ((400, 1300), 64)):
         A, b, c = dense_lp(m, n, seed=7 * m + n)
         st = lps.LPState(A, b, c, block=block, options=knobs)
         for k, v in knobs.items():
@@ -816,15 +816,22 @@ def test_cfg4_timed_form_70_pivots_vs_fp64_oracle(lps, oracle):
     print("cfg4 placement:", info)
 
 
+def test_cfg4_blocks_of_64_vs_fp64_oracle(lps, oracle):
+    """Opt-in blocks of 64 at BASELINE cfg4 size: one full block through the two-stage sweep kernel and the 64-slot
+    decision kernel, then a tail of 36 (two generic passes), against the fp64 oracle."""
+    info = _timed_form_vs_oracle(lps, oracle, 32768, 16384, (100,), options={"block": 64})
+    assert info["block"] == 64 and info["overlapped"] == 1
+
+
 @pytest.mark.parametrize("shape", [(2048, 4096), (4096, 8192), (8192, 2048)])
-@pytest.mark.parametrize("fences", [2, 3])
-def test_wide_decision_kernel_vs_oracle(lps, oracle, shape, fences):
+@pytest.mark.parametrize("fences,block", [(2, 32), (3, 32), (2, 64)])
+def test_wide_decision_kernel_vs_oracle(lps, oracle, shape, fences, block):
     """The decision kernel at full width (33 workgroups requested, clamped to what is resident) on 2-8 k-row
-    shapes, block 32, beside the sweeps: workgroup 0's one-way hand-off and the grid barrier run wide against
-    the oracle, in both barrier forms (acquire-only default, release + acquire)."""
+    shapes, block 32 (and the 64-slot form), beside the sweeps: workgroup 0's one-way hand-off and the grid barrier
+    run wide against the oracle, in both barrier forms (acquire-only default, release + acquire)."""
     m, n = shape
     A, b, c = dense_lp(m, n, seed=3 * m + n)
-    st = lps.LPState(A, b, c, block=32, options={"chain_wgs": 33, "chain_fences": fences})
+    st = lps.LPState(A, b, c, block=block, options={"chain_wgs": 33, "chain_fences": fences})
     ref = oracle.State(A, b, c, kind=oracle.FP64)
     for budget in (96, 45, 160):
         status, pivots, _ = st.simplex_loop(max_pivots=budget)
