@@ -486,7 +486,8 @@ int ensure_block_ring(lpx_state* s) {
   HIP_TRY(hipMemsetAsync(s->R.col0, 0, K * (size_t)mp * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.row0, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.up, K * sizeof(LpxCtl)));
-  HIP_TRY(hipMalloc(&s->R.chain_part_a, 2 * lpxk::kChainMaxWgs * 32));  // two sets, alternating by decision
+  HIP_TRY(hipMalloc(&s->R.chain_part_a, 2 * lpxk::kChainMaxWgs * 64));  // two sets, alternating by decision
+  HIP_TRY(hipMemsetAsync(s->R.chain_part_a, 0, 2 * lpxk::kChainMaxWgs * 64, s->stream));  // no tag of any launch
   HIP_TRY(hipMalloc(&s->R.chain_part_b, lpxk::kChainMaxWgs * 16));
   HIP_TRY(hipMalloc((void**)&s->R.chain_bar, 512));  // two barrier counters and the hand-off word, a line each
   HIP_TRY(hipMemsetAsync(s->R.chain_bar, 0, 512, s->stream));

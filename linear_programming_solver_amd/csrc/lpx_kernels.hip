@@ -787,10 +787,17 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
 // workgroups (the partial records, c[e], prow_s[e], col_s[l]) is read with agent-scope loads behind an agent-scope
 // release / acquire pair around the barrier's counter (MI355X: per-XCD L2s are not coherent with each other).
 // The arithmetic is statement for statement that of k_peek_multi / k_pack_multi / finish_pivot.
-struct ChainPart {
+struct ChainPart {   // 64 bytes per workgroup and decision parity (as a record, or as eight 8-byte granules)
   double ratio, a, bi;
   int32_t row, pad;
+  double unused[4];
 };
+#ifndef LPX_CHAIN_TAGGED
+#define LPX_CHAIN_TAGGED 1
+#endif
+__device__ __forceinline__ unsigned lo32(double x) { return (unsigned)__double2loint(x); }
+__device__ __forceinline__ unsigned hi32(double x) { return (unsigned)__double2hiint(x); }
+__device__ __forceinline__ double from32(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
 
 // ---- multi-device decisions -----------------------------------------------------------------------------------
 // Row-block shards on several GPUs of one node, one process (lpx_multi_*): every device runs this same persistent
@@ -976,6 +983,9 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
   static_assert(KB == 32 || KB == 64, "ring half of 32 or 64 slots");
   __shared__ RatioRow sh_rr[4];
   __shared__ unsigned long long sh_mask[2];
+#if LPX_CHAIN_TAGGED
+  __shared__ unsigned sh_gran[8], sh_part[kChainMaxWgs * 8];
+#endif
   __shared__ double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB], sh_win[2];
   __shared__ int sh_e[2 * KB], sh_l[2 * KB];
   __shared__ int sh_fail, sh_restart;
@@ -1082,6 +1092,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
       const RatioRow w = rr_block_min(best, sh_rr);
       if (w.row != INT_MAX && best.row == w.row) { sh_win[0] = best_a; sh_win[1] = best_b; }
       __syncthreads();
+#if !LPX_CHAIN_TAGGED
       if (tid == 0) {
         ChainPart* rec = &P.partA[(s & 1) * kChainMaxWgs + blockIdx.x];  // two sets: see the hand-off below
         st_agent(&rec->ratio, w.ratio);
@@ -1090,6 +1101,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         st_agent(&rec->bi, (w.row != INT_MAX) ? sh_win[1] : 0.0);
       }
     }
+    const unsigned xtag = P.hand_base + (unsigned)s;  // sequence number of this decision (unique over launches)
     if (P.dbg && lead) P.dbg[s * 5 + 1] = wall_clock64();
     target += (unsigned)G;
     if (!grid_barrier(P.bar, target, &sh_fail, P.fences)) {
@@ -1108,10 +1120,68 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
       mine_a = ld_agent(&rec->a);
       mine_b = ld_agent(&rec->bi);
     }
+#else
+      // The workgroup's candidate {ratio, a, b_row, row} goes out as seven self-validating 8-byte granules
+      // {32 data bits, sequence tag}, one aligned store each (MI355X_MICROARCH.md, hand-off by data-tagged granules):
+      // a reader that sees the tag has the data — no counter, no flag, no second read.  Stored only after every wave
+      // of the workgroup has drained its stores of this phase (col, col0: what later decisions read across
+      // workgroups), so seeing a record still implies what arriving at the counter barrier implied.
+      sh_gran[0] = lo32(w.ratio); sh_gran[1] = hi32(w.ratio);
+      const double wa = (w.row != INT_MAX) ? sh_win[0] : 0.0, wb = (w.row != INT_MAX) ? sh_win[1] : 0.0;
+      sh_gran[2] = lo32(wa); sh_gran[3] = hi32(wa); sh_gran[4] = lo32(wb); sh_gran[5] = hi32(wb);
+      sh_gran[6] = (unsigned)w.row;   // (every thread writes the same values)
+    }
+    const unsigned xtag = P.hand_base + (unsigned)s;  // sequence number of this decision (unique over launches)
+#ifndef LPX_CHAIN_DBG2
+    if (P.dbg && lead) P.dbg[s * 5 + 1] = wall_clock64();
+#endif
+    {
+      unsigned long long* const gran = reinterpret_cast<unsigned long long*>(P.partA) + (size_t)(s & 1) * kChainMaxWgs * 8;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid < 7) {
+        if (P.fences & 1) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __hip_atomic_store(&gran[blockIdx.x * 8 + tid], ((unsigned long long)xtag << 32) | sh_gran[tid], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int idx = tid; idx < G * 8; idx += 256) {   // one lane per granule of every workgroup's record
+        if ((idx & 7) == 7) continue;
+        unsigned long long g;
+        unsigned spins = 0;
+        while ((unsigned)((g = __hip_atomic_load(&gran[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != xtag) {
+          LPX_BARRIER_SLEEP;
+          if (++spins > (1u << 22)) { sh_fail = 1; break; }   // 1: a workgroup's candidate record
+        }
+        sh_part[idx] = (unsigned)g;
+      }
+      if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+      if (sh_fail) {
+        if (lead) { ctl->status = 7 /* LPX_DEVICE_ERROR */; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); }
+        return;
+      }
+    }
+#ifndef LPX_CHAIN_DBG2
+    if (P.dbg && lead) P.dbg[s * 5 + 2] = wall_clock64();
+#endif
+
+    // ------------------------------------------------------------------ phase B: the leaving row
+    RatioRow mine = rr_none();
+    double mine_a = 0.0, mine_b = 0.0;
+    if (tid < G) {
+      const unsigned* q = &sh_part[tid * 8];
+      mine.ratio = from32(q[0], q[1]);
+      mine_a = from32(q[2], q[3]);
+      mine_b = from32(q[4], q[5]);
+      mine.row = (int)q[6];
+    }
+#endif
     RatioRow w = rr_block_min(mine, sh_rr);
     if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
     __syncthreads();
-    const unsigned xtag = P.hand_base + (unsigned)s;  // sequence number of this decision (unique over launches)
     if constexpr (MG) {
       // The two mailbox slots alternate with the decisions of the whole LOOP, not of the launch: a device may be one
       // decision ahead of a peer — also across the boundary between two launches (a block of odd length would reuse
@@ -1201,6 +1271,9 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     const int rb = chain_restart<KB>(sh_mask);
     const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
     const int fn_b = rb >= KB ? rb - KB + 1 : 0;
+#ifdef LPX_CHAIN_DBG2   // diagnostic build: stamp 1 = leaving row known and its column values fetched
+    if (P.dbg && lead) P.dbg[s * 5 + 1] = wall_clock64();
+#endif
     const double bl = __ddiv_rn(raw_b, p);                                         // :146
     const double inv_p = __ddiv_rn(1.0, p);                                        // :139
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
@@ -1305,6 +1378,9 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         }
       }
     }
+#ifdef LPX_CHAIN_DBG2   // diagnostic build: stamp 2 = this thread's columns done (workgroup 0: word published)
+    if (P.dbg && lead) P.dbg[s * 5 + 2] = wall_clock64();
+#endif
     // the row owners add pivot s to their two running columns: the entering column after the pivot (what a later
     // decision restarts from) and b — after the columns, so that workgroup 0 publishes the entering slot first
     for (int i = gid; i < m; i += T) {
