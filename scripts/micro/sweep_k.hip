@@ -1,7 +1,7 @@
 // Sweep kernels alone on a synthetic ring: K = 64 pivots in one pass against two passes of 32 (bitwise the same
 // result, since an entry's update uses ring values only).  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 //   -I linear_programming_solver_amd/csrc scripts/micro/sweep_k.hip -o scripts/micro/sweep_k
-// Run: sweep_k [m] [n] [reps]
+// Run: sweep_k [m] [n] [reps] [rows per workgroup]
 #include "lpx_kernels.hip"
 
 #include <cstdio>
@@ -69,7 +69,6 @@ int main(int argc, char** argv) {
 
   Buffers B{}; B.ld = ld;
   BlockRing R{}; R.prow = prow; R.col = col; R.up = up; R.mp = mp;
-  BlockRing R2 = R; R2.prow = prow + 32 * ld; R2.col = col + 32 * mp; R2.up = up + 32;
   const int cus = 256;
   const int rows32 = std::max(48, choose_sweep_rows(m, ld, 32, cus) / 48 * 48);
   const int rows64 = argc > 4 ? atoi(argv[4]) : std::max(48, choose_sweep_rows(m, ld, 64, cus) / 48 * 48);
@@ -77,16 +76,14 @@ int main(int argc, char** argv) {
 
   // reference: two passes of 32 (out of place, then in place)
   B.A = ref;
-  auto two_pass = [&] {
-    launch_sweep_steady(B, R, m, 32, rows32, true, src, 0);
-    launch_sweep_k<32>(B, R, m, 32, rows32 / 64 * 64 > 0 ? std::max(64, rows32 / 64 * 64) : 64, true, src, 0, 1);
-    launch_sweep_steady(B, R2, m, 32, rows32, true, nullptr, 0);
-    launch_sweep_k<32>(B, R2, m, 32, std::max(64, rows32 / 64 * 64), true, nullptr, 0, 1);
+  auto two_pass = [&] {   // the generic kernel: slots 0..31 out of place, then slots 32..KT-1 in place
+    launch_sweep_k<32>(B, R, m, KT, std::max(64, rows32 / 64 * 64), true, src, 0, 0, 0);
+    launch_sweep_k<32>(B, R, m, KT, std::max(64, rows32 / 64 * 64), true, nullptr, 0, 0, 32);
   };
   // in-place second pass is not idempotent: time on a scratch copy, then recompute the reference once
   const float t32 = time_ms([&] {
     launch_sweep_steady(B, R, m, 32, rows32, true, src, 0);
-    launch_sweep_k<32>(B, R, m, 32, std::max(64, rows32 / 64 * 64), true, src, 0, 1);
+    launch_sweep_k<32>(B, R, m, 32, std::max(64, rows32 / 64 * 64), true, src, 0, 32);
   }, reps);
   two_pass();
   CK(hipDeviceSynchronize());
@@ -99,8 +96,8 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(&hb, bad, 8, hipMemcpyDeviceToHost));
   const double el = (double)m * ld;
   printf("K=32 one pass  %.3f ms  (%.2f TB/s, %.1f T lane-instr/s)\n", t32, 16 * el / t32 * 1e-9, 2 * el * 32 / t32 * 1e-9);
-  printf("K=64 one pass  %.3f ms  (%.2f TB/s, %.1f T lane-instr/s)   vs 2 x K=32 = %.3f ms\n", t64, 16 * el / t64 * 1e-9,
-         2 * el * 64 / t64 * 1e-9, 2 * t32);
+  printf("K=%d one pass  %.3f ms  (%.2f TB/s, %.1f T lane-instr/s)   vs %.1f x K=32 = %.3f ms\n", KT, t64, 16 * el / t64 * 1e-9,
+         2 * el * KT / t64 * 1e-9, KT / 32.0, KT / 32.0 * t32);
   printf("mismatching entries vs two passes of 32: %llu of %.0f\n", hb, el);
   // a few entries recomputed on the host (volatile: one rounding per operation)
   for (int t = 0; t < 6; ++t) {
