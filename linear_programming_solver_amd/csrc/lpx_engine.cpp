@@ -757,7 +757,10 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
 
 // LPSolver.simplex's loop with K pivot decisions per pass over the tableau (bit-identical results).
 static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
-  if (s->opt[LPX_OPT_CHAIN] != 0 && s->opt[LPX_OPT_OVERLAP] != 0 && s->row0 == 0 && s->m == s->m_global) {
+  // a budget that fits one block has nothing to run beside: the serial form below gives its decisions and its sweep
+  // the whole chip (20 pivots, the bench driver's command: cfg3 24.7k vs 20.0k pivots/s, same box)
+  const bool one_block = max_pivots >= 0 && max_pivots + 1 <= K;
+  if (s->opt[LPX_OPT_CHAIN] != 0 && s->opt[LPX_OPT_OVERLAP] != 0 && s->row0 == 0 && s->m == s->m_global && !one_block) {
     // the overlapped form needs a second tableau: a tableau of more than half the HBM keeps the in-place form
     if (s->A2 || ensure_spare_tableau(s) == 0) return blocked_loop_overlapped(s, K, max_pivots);
     (void)hipGetLastError();

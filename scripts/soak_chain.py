@@ -26,7 +26,7 @@ def main():
     n_lp = n_cmp = pivots_total = 0
     while time.time() < t_end:
         m, n = shapes[n_lp % len(shapes)]
-        block = int(rng.choice([8, 16, 32]))
+        block = int(rng.choice([8, 16, 32, 32, 64]))
         A = rng.random((m, n))
         b = (n / 4.0) * (1.0 + rng.random(m))
         c = rng.random(n)

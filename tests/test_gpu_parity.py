@@ -808,9 +808,10 @@ def test_cfg3_timed_form_200_pivots_vs_fp64_oracle(lps, oracle):
 
 
 def test_cfg4_timed_form_70_pivots_vs_fp64_oracle(lps, oracle):
-    """BASELINE cfg4 (32768 x 16384, 4 GiB): two full K = 32 blocks + a tail through the default loop, then 25 more
-    (the driver's bench command is 5 + 20 pivots), every time against the fp64 oracle."""
-    info = _timed_form_vs_oracle(lps, oracle, 32768, 16384, (70, 25))
+    """BASELINE cfg4 (32768 x 16384, 4 GiB): 25 pivots (the driver's bench command is 5 + 20: a budget that fits one
+    block goes through the serial form on the whole chip), then two full K = 32 blocks + a tail through the default
+    overlapped loop, every time against the fp64 oracle."""
+    info = _timed_form_vs_oracle(lps, oracle, 32768, 16384, (25, 70))
     assert info["block"] == 32 and info["overlapped"] == 1 and info["nontemporal"] == 1
     assert info["chain_wgs"] <= info["chain_resident_max"]
     print("cfg4 placement:", info)
