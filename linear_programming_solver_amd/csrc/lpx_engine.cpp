@@ -506,6 +506,7 @@ int ensure_block_ring(lpx_state* s) {
   HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.up, 0, K * sizeof(LpxCtl), s->stream));
   HIP_TRY(hipMemsetAsync(s->d_cand, 0, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double), s->stream));
+  lpxk::preload_block_kernels(s->B, s->R, s->stream);
   return 0;
 }
 

@@ -130,6 +130,9 @@ struct MgPeers {
 void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
                         int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
                         hipStream_t s, const MgPeers* mg = nullptr);
+// one trivial launch of every kernel of the blocked loop, once per device (the runtime prepares a kernel at its first
+// launch); needs the handle's buffers and its ring (with chain_bar) allocated
+void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s);
 // hipOccupancyMaxActiveBlocksPerMultiprocessor for k_block_chain (256 threads, its static LDS); >= 1
 int chain_blocks_per_cu();
 // apply the valid leading pending pivots (at most K) in one pass

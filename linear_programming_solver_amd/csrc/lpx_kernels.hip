@@ -17,6 +17,8 @@
 // hot expressions use __dmul_rn/__dsub_rn/__dadd_rn/__ddiv_rn so that no FMA can be formed.
 #include "lpx_kernels.h"
 
+#include <atomic>
+
 #include <limits.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1706,14 +1708,14 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
                                                       int slot0) {
   // slot0: this pass applies the pending pivots slot0 .. slot0 + K - 1 of the block (a block of more than 32 goes in
   // two passes where the one-pass kernel does not apply); the rings are passed at slot 0, kmax counts from slot 0.
-  // complement (0, or the block length the steady-state kernel needs): that kernel has taken the full strips of a
-  // full block, only what it leaves is done here.
+  // complement (0, or the smallest number of valid pivots at which the steady-state kernel launched in front takes
+  // the full strips: 1 for k_sweep32_steady, 64 for k_sweep64_pipe): only what that kernel leaves is done here.
   __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
   constexpr int CH = kSweepChunk;
   if (complement) {
     const int np0 = ring_count(ring, kBlockMax, kmax, &sh_np);
-    if (np0 == complement && (blockIdx.x % nstrips + 1) * 512 <= (int)ld) return;
+    if (np0 >= complement && (blockIdx.x % nstrips + 1) * 512 <= (int)ld) return;
     __syncthreads();
   }
   prow_ring += (int64_t)slot0 * ld;
@@ -1911,7 +1913,12 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ 
   static_assert((CH / RB) % NB == 0 && 2 * CH <= kSweepMaxRows && K * CH % 256 == 0, "chunk geometry");
   __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
-  if (ring_count(ring, K, kmax, &sh_np) != K) return;   // a partly filled block: k_update_multi takes all of it
+  // A partly filled block (np < 32: it ended early, or it is the tail of a pivot budget) runs the same straight-line
+  // code: the steps np..31 get the multiplier +0 AND the pivot-row slice +0, and x - (+0 * +0) = x - (+0) = x bit for
+  // bit for every x (-0, infinities and NaNs included) — identities instead of branches.  Below ~16 pivots the time is
+  // the memory's either way.  An empty block is left to k_update_multi (out of place it still carries the tableau over).
+  const int np = ring_count(ring, K, kmax, &sh_np);
+  if (np == 0) return;
   const int strip = blockIdx.x % nstrips_full;
   const int grp = blockIdx.x / nstrips_full;
   const int cj = strip * 512 + 2 * threadIdx.x;
@@ -1929,11 +1936,14 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ 
   // prologue with ordinary loads: chunk 0's multipliers, the thread's 32 pivot-row slices, batches 0 and 1
   for (int idx = threadIdx.x; idx < K * CH; idx += 256) {
     const int sidx = idx / CH, r = idx % CH;
-    sh_col[sidx][r] = (r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;
+    sh_col[sidx][r] = (r < nrows && sidx < np) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;
   }
   d2 pr[K];
 #pragma unroll
-  for (int s = 0; s < K; ++s) pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj);
+  for (int s = 0; s < K; ++s) {
+    pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj);
+    if (s >= np) pr[s] = d2{0.0, 0.0};   // uniform
+  }
   d2 xb[NB][RB];
 #pragma unroll
   for (int u = 0; u < NB; ++u)
@@ -1959,7 +1969,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ 
         const int idx = threadIdx.x + k * 256;
         const int sidx = idx / CH, r = idx % CH;
         colpf[k] = 0.0;
-        if (r < n_next)
+        if (r < n_next && sidx < np)
           strip_load8(colpf[k], col_base, (uint32_t)(((int64_t)sidx * mp + (ch + 1) * CH + r) * 8));
       }
     }
@@ -2479,6 +2489,57 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   }
 }
 
+// The runtime prepares a kernel for a device the first time it is LAUNCHED (looking the function up does not do it;
+// measured on MI355X boxes: 0.2-0.3 ms on the first block that uses the steady-state sweep kernel, i.e. a tenth of a
+// block's time at cfg4).  A loop whose first blocks have another length than its later ones (a short warm-up, the tail
+// of a budget) would pay that inside its own run, so every kernel of the blocked loop is launched once per device
+// when the first ring is built — one workgroup each, with arguments that make it return at once (no pending pivots,
+// no rows, no decisions) and touch nothing but the ring's own words.
+void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) {
+  static std::atomic<unsigned> done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return;
+  if (done.fetch_or(1u << dev) & (1u << dev)) return;
+  double* const A = B.A;
+  const int64_t ld = B.ld;
+  unsigned* const no_census = nullptr;
+#define LPX_EACH_NT_OOP(X) X(true, true) X(true, false) X(false, true) X(false, false)
+#define LPX_PRE_TILES(K_, NT_, OOP_) \
+  hipLaunchKernelGGL((k_update_tiles<K_, NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 16, 1, no_census);
+#define LPX_PRE_T2(NT_, OOP_) LPX_PRE_TILES(2, NT_, OOP_)
+#define LPX_PRE_T4(NT_, OOP_) LPX_PRE_TILES(4, NT_, OOP_)
+#define LPX_PRE_T8(NT_, OOP_) LPX_PRE_TILES(8, NT_, OOP_)
+#define LPX_PRE_T16(NT_, OOP_) LPX_PRE_TILES(16, NT_, OOP_)
+#define LPX_PRE_T32(NT_, OOP_) LPX_PRE_TILES(32, NT_, OOP_)
+#define LPX_PRE_MULTI(NT_, OOP_) \
+  hipLaunchKernelGGL((k_update_multi<32, NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 64, 1, no_census, 0, 0);
+#define LPX_PRE_STEADY(NT_, OOP_) \
+  hipLaunchKernelGGL((k_sweep32_steady<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 48, 1);
+#define LPX_PRE_PIPE(NT_, OOP_) \
+  hipLaunchKernelGGL((k_sweep64_pipe<NT_, OOP_>), dim3(1), dim3(512), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 48, 1);
+  LPX_EACH_NT_OOP(LPX_PRE_T2) LPX_EACH_NT_OOP(LPX_PRE_T4) LPX_EACH_NT_OOP(LPX_PRE_T8) LPX_EACH_NT_OOP(LPX_PRE_T16)
+  LPX_EACH_NT_OOP(LPX_PRE_T32) LPX_EACH_NT_OOP(LPX_PRE_MULTI) LPX_EACH_NT_OOP(LPX_PRE_STEADY) LPX_EACH_NT_OOP(LPX_PRE_PIPE)
+#undef LPX_PRE_PIPE
+#undef LPX_PRE_STEADY
+#undef LPX_PRE_MULTI
+#undef LPX_PRE_T32
+#undef LPX_PRE_T16
+#undef LPX_PRE_T8
+#undef LPX_PRE_T4
+#undef LPX_PRE_T2
+#undef LPX_PRE_TILES
+#undef LPX_EACH_NT_OOP
+  hipLaunchKernelGGL(k_block_fixup, dim3(1, 1, 3), dim3(256), 0, s, A, ld, 0, 0, 0, B.b, R.prow, R.col, R.col0, R.row0,
+                     R.mp, R.up, 0, B.b);
+  ChainArgs P{};   // nb = 0: every workgroup returns after reading the loop state (no barrier, nothing published)
+  P.ctl = B.ctl; P.up = R.up; P.nb = 0;
+  P.bar = R.chain_bar; P.bar_next = R.chain_bar + 32;
+  hipLaunchKernelGGL((k_block_chain_t<false, 32>), dim3(1), dim3(256), 0, s, P);
+  hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(1), dim3(256), 0, s, P);
+  hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(1), dim3(256), 0, s, P);
+  (void)hipGetLastError();
+}
+
 int chain_blocks_per_cu() {
   int nb = 0;
   int nw = 0;
@@ -2627,10 +2688,13 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, pipe ? 64 : 0, 0);
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, pipe ? 64 : 0, 32);
     rows_per_wg = pipe ? rows64 : rows;
-  } else if (K < kMaxBlock) {
-    // a partly filled block of 17..31 pivots (the tail of a pivot budget): the tile kernel's guarded path took such
-    // blocks faster than the long-run kernel's (cfg3, 20 pivots, same box: 490 vs 615 us); 64-row tiles as long as the
-    // grid keeps a few thousand workgroups (profiles/r01_sweep_rows.txt)
+#ifndef LPX_STEADY_PARTIAL
+#define LPX_STEADY_PARTIAL 1
+#endif
+  } else if (K < kMaxBlock && !(LPX_STEADY_PARTIAL && m_local % 4 == 0 && B.ld >= 512)) {
+    // a partly filled block of 17..31 pivots (the tail of a pivot budget) where the hand-pipelined kernel does not
+    // apply: the tile kernel's guarded path took such blocks faster than the long-run kernel's (cfg3, 20 pivots, same
+    // box: 490 vs 615 us); 64-row tiles as long as the grid keeps a few thousand workgroups (profiles/r01_sweep_rows.txt)
     const int64_t nstrips = (B.ld + 511) / 512;
     int rows_per_tile = 16;
     for (int rows : {64, 32})
@@ -2649,7 +2713,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
       // the partial last strip — by the generic kernel, which skips what the first one took
       const int rows48 = std::max(48, rows_per_wg / 48 * 48);
       launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
-      launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 32);
+      launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);
     } else
 #endif
       launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s);
