@@ -817,6 +817,13 @@ def test_cfg4_timed_form_70_pivots_vs_fp64_oracle(lps, oracle):
     print("cfg4 placement:", info)
 
 
+def test_tableau_beyond_4_gib_vs_fp64_oracle(lps, oracle):
+    """36864 x 18432 = 5.4 GB per tableau buffer: byte offsets beyond 2^32 in the sweeps (32-bit offsets are per run of
+    rows only), the decision kernel's strided column reads and the fix-up, 40 pivots through the default loop."""
+    info = _timed_form_vs_oracle(lps, oracle, 36864, 18432, (40,))
+    assert info["block"] == 32 and info["overlapped"] == 1
+
+
 def test_cfg4_blocks_of_64_vs_fp64_oracle(lps, oracle):
     """Opt-in blocks of 64 at BASELINE cfg4 size: one full block through the two-stage sweep kernel and the 64-slot
     decision kernel, then a tail of 36 (two generic passes), against the fp64 oracle."""
