@@ -299,6 +299,29 @@ def test_cfg2_full_solve_matches_fp64_oracle_bit_for_bit(lps, oracle):
     st.close()
 
 
+@pytest.mark.parametrize("m,n,seed", [(12, 9, 1), (80, 120, 4), (200, 260, 6), (33, 257, 7), (257, 33, 8), (600, 900, 9)])
+def test_solve_optimum_equals_highs_optimum(lps, m, n, seed):
+    """Independent of the oracle: lpx_solve's optimum, its solution vector and its unbounded verdict against SciPy's
+    HiGHS on seeded random LPs with a feasible start (tests/test_oracle_vs_highs.py holds the generator and the
+    reasoning); 1e-9 relative on the objective, x* feasible and reaching the same objective."""
+    from tests.test_oracle_vs_highs import TOL, highs, random_feasible_start_lp
+    A, b, c = random_feasible_start_lp(m, n, seed)
+    status, want = highs(A, b, c)
+    assert status == 0
+    solver = lps.LPSolver()
+    solver.solve(lps.LPStandardForm(A, b, c, maximize=True))
+    got = solver.last
+    assert got.status == 0 and not got.phase1_used
+    assert abs(got.objective - want) <= TOL * max(1.0, abs(want)), (got.objective, want)
+    x = got.x
+    assert np.all(x >= 0.0) and np.all(A @ x <= b + 1e-9 * (1.0 + np.abs(b)))
+    assert abs(float(c @ x) - want) <= 1e-8 * max(1.0, abs(want))
+    Au, bu, cu = random_feasible_start_lp(m, n, seed + 100, bounded=False)
+    assert highs(Au, bu, cu)[0] == 3
+    with pytest.raises(lps.SolutionException):       # "This linear program is unbounded", LPSolver.java:105
+        lps.LPSolver().solve(lps.LPStandardForm(Au, bu, cu, maximize=True))
+
+
 def test_cfg2_first_pivots_follow_the_decimal_reference(lps, oracle):
     """At cfg2 the decimal-15 oracle (reference arithmetic) is too slow for a full solve; it pins the first
     pivots: same (entering, leaving) sequence, objective within OBJ_TOL."""
