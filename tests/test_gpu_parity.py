@@ -322,6 +322,21 @@ def test_solve_optimum_equals_highs_optimum(lps, m, n, seed):
         lps.LPSolver().solve(lps.LPStandardForm(Au, bu, cu, maximize=True))
 
 
+@pytest.mark.parametrize("m,n,seed", [(6, 5, 31), (25, 40, 32), (90, 60, 33), (300, 500, 34)])
+def test_solve_reports_infeasible_where_highs_does(lps, m, n, seed):
+    """Phase 1 on the device against an independent solver: a random LP with a contradictory pair of rows must end
+    in LPException("This linear program is infeasible") (LPSolver.java:171-174), on one GPU and on row-block shards."""
+    from tests.test_oracle_vs_highs import highs, random_infeasible_lp
+    A, b, c = random_infeasible_lp(m, n, seed)
+    assert highs(A, b, c)[0] == 2
+    for devices in (None, [0, 0]):
+        solver = lps.LPSolver(devices=devices)
+        with pytest.raises(lps.LPException) as err:
+            solver.solve(lps.LPStandardForm(A, b, c, maximize=True))
+        assert not isinstance(err.value, lps.SolutionException)
+        assert solver.last.status == 2 and solver.last.phase1_used
+
+
 def test_cfg2_first_pivots_follow_the_decimal_reference(lps, oracle):
     """At cfg2 the decimal-15 oracle (reference arithmetic) is too slow for a full solve; it pins the first
     pivots: same (entering, leaving) sequence, objective within OBJ_TOL."""

@@ -70,3 +70,27 @@ def test_minimisation_goes_through_the_same_path(oracle):
     st.close()
     assert res["status"] == 0
     assert abs(res["objective"] - res_h.fun) <= TOL * max(1.0, abs(res_h.fun))
+
+
+def random_infeasible_lp(m, n, seed):
+    """A random LP with b of mixed sign (phase 1 runs) made infeasible by one contradictory pair of rows:
+    w.x <= 1 and -w.x <= -3 with w > 0.  The verdict comes out of phase 1 alone (x0 > 0 at the auxiliary optimum,
+    LPSolver.java:168-173), before restoreInitialLP is ever reached."""
+    rng = np.random.default_rng(seed)
+    A = rng.random((m, n)) * 1.5 - 0.5
+    b = rng.random(m) * 3.0 - 1.0
+    c = rng.random(n)
+    w = 0.5 + rng.random(n)
+    A[0, :], b[0] = w, 1.0
+    A[1, :], b[1] = -w, -3.0
+    return A, b, c
+
+
+@pytest.mark.parametrize("m,n,seed", [(6, 5, 31), (25, 40, 32), (90, 60, 33)])
+def test_oracle_reports_infeasible_where_highs_does(oracle, m, n, seed):
+    A, b, c = random_infeasible_lp(m, n, seed)
+    assert highs(A, b, c)[0] == 2      # HiGHS: infeasible
+    for kind in (oracle.FP64, oracle.DEC15):
+        res, st = oracle.solve(A, b, c, maximize=True, kind=kind, want_trace=False)
+        st.close()
+        assert res["phase1_used"] and res["status"] == 2, (m, n, seed, kind, res["status"])   # LPX_INFEASIBLE
