@@ -2633,10 +2633,14 @@ static int choose_sweep_rows(int m_local, int64_t ld, int K, int cus) {
 // Rows per workgroup of the two-stage kernel: one 512-thread workgroup per CU at a time, so the grid should be a
 // whole number of rounds of `cus` workgroups (cfg4 alone on the chip: 1024 rows = 4 full rounds 2.83 ms, 672 rows =
 // 6.1 rounds 3.29 ms); three or more rounds when there is enough work, so that uneven CUs even out.
-static int choose_pipe_rows(int m_local, int nstrips_full, int cus) {
-  const int prologue_rows = 96;   // the run's pivot-row slices and first multipliers, in rows' worth of time
+// `slots` = workgroups resident at once (one per CU for the two-stage kernel, two for k_sweep32_steady, whose runs
+// take ~0.6 ms each at cfg4: 2.86 rounds of 832-row runs cost what 3 rounds do, 1.80 ms, where 3 exact rounds of
+// 784-row runs take 1.70 ms).
+static int choose_pipe_rows(int m_local, int nstrips_full, int slots, int prologue_rows = 96) {
+  // prologue_rows: the run's pivot-row slices and first multipliers, in rows' worth of time
   int best_rows = std::max(4, (m_local + 3) / 4 * 4);
   int64_t best_cost = INT64_MAX;
+  const int cus = std::max(1, slots);
   for (int rounds = 1; rounds <= 8; ++rounds) {
     const int64_t groups = std::max<int64_t>(1, (int64_t)rounds * cus / std::max(1, nstrips_full));
     const int rows = (int)(((m_local + groups - 1) / groups + 3) / 4 * 4);
@@ -2704,6 +2708,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     rows_per_wg = rows_per_tile;
   } else {
     // long runs of rows per workgroup (k_update_multi): the 2K doubles of pivot-row slices are fetched once per run
+    const bool rows_given = rows_per_wg > 0;
     if (rows_per_wg <= 0) rows_per_wg = choose_sweep_rows(m_local, B.ld, K, cus);
     rows_per_wg = std::max(kSweepChunk, (rows_per_wg + kSweepChunk - 1) / kSweepChunk * kSweepChunk);
     while (rows_per_wg > kSweepChunk && (int64_t)rows_per_wg * B.ld * 8 >= (int64_t)1 << 32) rows_per_wg -= kSweepChunk;  // 32-bit offsets
@@ -2711,9 +2716,17 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     if (m_local % 4 == 0 && B.ld >= 512) {
       // full block over the full strips: hand-pipelined kernel (48-row chunks); the rest — a block that ends early,
       // the partial last strip — by the generic kernel, which skips what the first one took
-      const int rows48 = std::max(48, rows_per_wg / 48 * 48);
+#ifndef LPX_STEADY_EXACT_ROUNDS
+#define LPX_STEADY_EXACT_ROUNDS 1
+#endif
+      int rows48 = std::max(48, rows_per_wg / 48 * 48);
+      if (LPX_STEADY_EXACT_ROUNDS && !rows_given) {   // whole rounds of two workgroups per CU over the full strips
+        rows48 = choose_pipe_rows(m_local, (int)(B.ld / 512), 2 * cus, 48);
+        while (rows48 > 4 && (int64_t)rows48 * B.ld * 8 >= (int64_t)1 << 32) rows48 -= 4;   // 32-bit offsets
+      }
       launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
       launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);
+      rows_per_wg = rows48;   // (what lpx_state_get_info reports: the kernel that did the work)
     } else
 #endif
       launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s);
