@@ -1897,9 +1897,27 @@ __device__ __forceinline__ void strip_load16(d2& x, const char* base, uint32_t o
 __device__ __forceinline__ void strip_load8(double& x, const char* base, uint32_t off) {
   asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(x) : "v"(off), "s"(base) : "memory");
 }
+// The wait is TWO statements with a scheduling barrier between them.  A single asm with the registers as in/out
+// operands is not enough: the register allocator may give the asm other registers than the loads' destinations and
+// copy the (not yet arrived) contents over BEFORE the statement — seen in the vmcnt(0) path at the end of a run,
+// where one wave's last batches then came out stale about once in 15 000 runs of a workgroup.  Here the counter is
+// waited for first; nothing crosses the barrier; only then a second, empty asm hands the registers to the compiler
+// (any copy it makes for that statement sits after the barrier, i.e. after the data has arrived).
+// all_follow (uniform): the N younger operations the count assumes have all been issued; otherwise (the last batches
+// of a run) everything is waited for.  One hand-over statement for both cases: no merge of two register assignments.
 template <int N>
-__device__ __forceinline__ void strip_wait4(d2 (&x)[4]) {
-  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N) : "memory");
+__device__ __forceinline__ void strip_wait4(d2 (&x)[4], bool all_follow) {
+  if (all_follow) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) :: "memory");
+}
+template <int N, int PF>
+__device__ __forceinline__ void strip_wait_parked(double (&x)[PF]) {
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < PF; ++k) asm volatile("" : "+v"(x[k]) :: "memory");
 }
 
 template <bool NT, bool OOP>
@@ -1988,8 +2006,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ 
           }
           if (bt + u >= NB - 1) {
             // younger than this batch's loads: RB stores and RB loads per batch in between, NB - 1 batches
-            if (ahead) strip_wait4<2 * RB * (NB - 1)>(xb[u]);
-            else strip_wait4<0>(xb[u]);   // the tail of the run: fewer operations follow
+            strip_wait4<2 * RB * (NB - 1)>(xb[u], ahead);   // (the tail of the run: fewer operations follow)
           }
           sweep_apply<K, RB, kSweepAll>(xb[u], pr, sh_col, K, half + r0 % CH);
 #pragma unroll
@@ -2002,9 +2019,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ 
     }
     if (more) {
       // 96 memory operations were issued after the multiplier requests: they are long back (vmcnt is 6 bits wide)
-      asm volatile("s_waitcnt vmcnt(32)"
-                   : "+v"(colpf[0]), "+v"(colpf[1]), "+v"(colpf[2]), "+v"(colpf[3]), "+v"(colpf[4]), "+v"(colpf[5])
-                   :: "memory");
+      strip_wait_parked<32, PF>(colpf);
 #pragma unroll
       for (int k = 0; k < PF; ++k) {
         const int idx = threadIdx.x + k * 256;
@@ -2107,8 +2122,7 @@ __global__ __launch_bounds__(512) void k_sweep64_pipe(double* __restrict__ A, co
             if (it >= NB - 1) {
               // younger than this batch's loads: the RB loads of each of the NB - 1 batches behind it (this stage
               // stores nothing; parked multiplier requests in between only make the wait stricter)
-              if (ahead) strip_wait4<RB * (NB - 1)>(xb[u]);
-              else strip_wait4<0>(xb[u]);
+              strip_wait4<RB * (NB - 1)>(xb[u], ahead);
             }
             sweep_apply<KS, RB, kSweepAll>(xb[u], pr, my_col, KS, half + r0 % CH);
 #pragma unroll
@@ -2132,9 +2146,7 @@ __global__ __launch_bounds__(512) void k_sweep64_pipe(double* __restrict__ A, co
     if (more) {
       // >= 44 memory operations were issued after the multiplier requests (48 loads by stage 0; the stores of 11 or
       // 12 batches by stage 1): they are long back (vmcnt counts in issue order)
-      asm volatile("s_waitcnt vmcnt(32)"
-                   : "+v"(colpf[0]), "+v"(colpf[1]), "+v"(colpf[2]), "+v"(colpf[3]), "+v"(colpf[4]), "+v"(colpf[5])
-                   :: "memory");
+      strip_wait_parked<32, PF>(colpf);
 #pragma unroll
       for (int k = 0; k < PF; ++k) {
         const int idx = threadIdx.x + k * 512;

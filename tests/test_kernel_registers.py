@@ -52,3 +52,45 @@ def test_default_decision_kernel_has_no_scratch(device_asm):
     assert len(res) == 2, sorted(res)   # one device / shards of an lpx_multi
     for name, r in res.items():
         assert r["private_seg_size"] == 0, (name, r)
+
+
+def _kernel_bodies(asm, kernel):
+    """{mangled name: [instruction lines]} of every instantiation of `kernel` (labels and comments kept)."""
+    out = {}
+    for m in re.finditer(r"^(\S*%s\S*):\s*(?:;.*)?$" % kernel, asm, flags=re.M):
+        end = asm.find("s_endpgm", m.end())
+        out[m.group(1)] = [ln.strip() for ln in asm[m.end():end].splitlines()]
+    return out
+
+
+@pytest.mark.parametrize("kernel", ["k_sweep32_steady", "k_sweep64_pipe"])
+def test_no_register_copy_sits_in_front_of_a_hand_written_wait(device_asm, kernel):
+    """The hand-written `s_waitcnt vmcnt(N)` must come before ANY copy of the registers its loads are landing in.
+    (A single asm with the registers as in/out operands let the allocator copy them in front of the statement: one
+    wave's last batches of a run then came out stale once in ~15 000 workgroup runs.)  Within a basic block, between
+    the previous asm statement (or the block's label) and a hand-written wait there must be no vector move."""
+    bodies = _kernel_bodies(device_asm, kernel)
+    assert len(bodies) == 4, sorted(bodies)
+    for name, lines in bodies.items():
+        waits = 0
+        since = []          # instructions since the last label / asm statement
+        in_asm = False
+        for ln in lines:
+            if ln.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if ln.startswith(";;#ASMEND"):
+                in_asm = False
+                since = []
+                continue
+            if in_asm:
+                if ln.startswith("s_waitcnt vmcnt"):
+                    waits += 1
+                    moves = [x for x in since if x.startswith(("v_mov", "v_accvgpr", "scratch_"))]
+                    assert not moves, (name, ln, moves)
+                continue
+            if ln.endswith(":") or ln.startswith(".LBB"):
+                since = []
+            elif ln and not ln.startswith(";"):
+                since.append(ln)
+        assert waits >= 3, (name, waits)
