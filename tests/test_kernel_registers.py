@@ -94,3 +94,46 @@ def test_no_register_copy_sits_in_front_of_a_hand_written_wait(device_asm, kerne
             elif ln and not ln.startswith(";"):
                 since.append(ln)
         assert waits >= 3, (name, waits)
+
+
+def _regs(operand):
+    """VGPR numbers named by an operand such as v12 or v[34:37] (empty for anything else)."""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", operand)
+    return {int(m.group(1))} if m else set()
+
+
+@pytest.mark.parametrize("kernel", ["k_sweep32_steady", "k_sweep64_pipe"])
+def test_no_register_copy_reads_a_hand_issued_load_before_its_wait(device_asm, kernel):
+    """The other half of the same hazard: after a hand-issued `global_load` nothing may read its destination
+    registers before a hand-written wait has been passed.  Checked in program order (the kernels' loops keep loads
+    and the wait that covers them in straight succession): between an asm load and the next asm `s_waitcnt vmcnt`
+    no move, scratch store or AGPR write may name a register the load is landing in."""
+    bodies = _kernel_bodies(device_asm, kernel)
+    for name, lines in bodies.items():
+        landing = set()
+        in_asm = False
+        loads = 0
+        for ln in lines:
+            if ln.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if ln.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if in_asm:
+                if ln.startswith("global_load_dword"):
+                    landing |= _regs(ln.split()[1].rstrip(","))
+                    loads += 1
+                elif ln.startswith("s_waitcnt vmcnt(0)"):
+                    landing = set()       # (a partial wait covers the older loads only: keep the set)
+                continue
+            if ln.startswith(("v_mov", "v_accvgpr_write", "scratch_store")):
+                ops = [o.strip() for o in ln.split(None, 1)[1].split(",")]
+                read = set().union(*[_regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+                if ln.startswith("scratch_store"):
+                    read = set().union(*[_regs(o) for o in ops])
+                assert not (read & landing), (name, ln, sorted(read & landing))
+        assert loads >= 8, (name, loads)
