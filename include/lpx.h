@@ -165,8 +165,8 @@ int lpx_state_read_chain_trace(lpx_state* s, int64_t* ticks, int32_t cap, int32_
  * taken from the not-yet-updated tableau (each needs one column and one row, recovered by the pending pivots'
  * rank-1 formulas) and then applied in ONE sweep that runs every entry through the K updates in order —
  * bit-identical to K separate updates, 1/K of the HBM traffic per pivot.  0 = choose by size (default),
- * 1 = off (one update pass per pivot), 2..64 = fixed (powers of two sweep fastest; the by-size choice stops at 32:
- * blocks of 33..64 use a two-stage sweep and 64-slot decisions, worth +3..5 % only on tableaux of 4 GiB and more;
+ * 1 = off (one update pass per pivot), 2..64 = fixed (powers of two sweep fastest; the by-size choice is 32 up to
+ * ~7 GiB of tableau and 64 above: blocks of 33..64 use a two-stage sweep and 64-slot decisions, worth +3..5 % from 4 GiB;
  * shards and lpx_multi handles, and the loop with LPX_OPT_CHAIN = 0, use at most 32).  On an unsharded handle the
  * K decisions are one persistent launch and run beside the previous block's sweep, which then works out of place:
  * the handle allocates a second tableau (same size) at the first blocked loop. */

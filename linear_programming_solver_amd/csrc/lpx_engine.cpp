@@ -540,9 +540,11 @@ int choose_block(const lpx_state* s) {
     if (sweep_us < 15.0) K = 1;        // cache-resident tableaux: the two-launch loop wins
     else if (sweep_us < 250.0) K = 16;
     else K = 32;
-    // 64 (opt-in): the two-stage sweep moves half the bytes per pivot and takes 0.74x the time per pivot alone on the
-    // chip, but 64-slot decisions cost twice as much each (their ring reads grow with K^2) and take bandwidth from the
-    // sweep beside them: +3..5 % over 32 from 4 GiB to 12 GiB tableaux (profiles/r02_block64_policy.txt), -22 % at 2 GiB
+    // 64: the two-stage sweep moves half the bytes per pivot and takes 0.74x the time per pivot alone on the chip, but
+    // 64-slot decisions cost twice as much each (their ring reads grow with K^2) and take bandwidth from the sweep
+    // beside them: +3..5 % over 32 from 4 GiB to 12 GiB tableaux (profiles/r02_block64_policy.txt), -22 % at 2 GiB.
+    // By size only from ~7 GiB up (8 GiB +4.3 %, 12 GiB +5.4 %), where the kernel applies; opt-in below.
+    if (sweep_us >= 2500.0 && s->m % 4 == 0 && s->B.ld >= 512) K = 64;
   }
   // three launches per decision (option chain = 0, the form the shards use): its kernels hold at most 32 pending pivots
   if (!s->opt[LPX_OPT_CHAIN] || s->m_global != s->m) K = std::min(K, (int)lpxk::kShardBlockMax);

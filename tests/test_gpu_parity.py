@@ -862,6 +862,13 @@ def test_tableau_beyond_4_gib_vs_fp64_oracle(lps, oracle):
     assert info["block"] == 32 and info["overlapped"] == 1
 
 
+def test_8_gib_tableau_takes_blocks_of_64_by_size(lps, oracle):
+    """40960 x 24576 = 8.05 GB per tableau buffer: above ~7 GiB the by-size choice is blocks of 64 (two-stage sweep,
+    64-slot decisions); one full block + a tail of 6 against the fp64 oracle."""
+    info = _timed_form_vs_oracle(lps, oracle, 40960, 24576, (70,))
+    assert info["block"] == 64 and info["overlapped"] == 1
+
+
 def test_cfg4_blocks_of_64_vs_fp64_oracle(lps, oracle):
     """Opt-in blocks of 64 at BASELINE cfg4 size: one full block through the two-stage sweep kernel and the 64-slot
     decision kernel, then a tail of 36 (two generic passes), against the fp64 oracle."""
