@@ -1708,14 +1708,15 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
                                                       int slot0) {
   // slot0: this pass applies the pending pivots slot0 .. slot0 + K - 1 of the block (a block of more than 32 goes in
   // two passes where the one-pass kernel does not apply); the rings are passed at slot 0, kmax counts from slot 0.
-  // complement (0, or the smallest number of valid pivots at which the steady-state kernel launched in front takes
-  // the full strips: 1 for k_sweep32_steady, 64 for k_sweep64_pipe): only what that kernel leaves is done here.
+  // complement (0, or 1 + the smallest number of valid pivots at which the steady-state kernel launched in front takes
+  // the full strips: 1 for k_sweep32_steady — it takes them always —, 65 for k_sweep64_pipe): only what that kernel
+  // leaves is done here.
   __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
   __shared__ int sh_np;
   constexpr int CH = kSweepChunk;
   if (complement) {
     const int np0 = ring_count(ring, kBlockMax, kmax, &sh_np);
-    if (np0 >= complement && (blockIdx.x % nstrips + 1) * 512 <= (int)ld) return;
+    if (np0 >= complement - 1 && (blockIdx.x % nstrips + 1) * 512 <= (int)ld) return;
     __syncthreads();
   }
   prow_ring += (int64_t)slot0 * ld;
@@ -1934,9 +1935,9 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ 
   // A partly filled block (np < 32: it ended early, or it is the tail of a pivot budget) runs the same straight-line
   // code: the steps np..31 get the multiplier +0 AND the pivot-row slice +0, and x - (+0 * +0) = x - (+0) = x bit for
   // bit for every x (-0, infinities and NaNs included) — identities instead of branches.  Below ~16 pivots the time is
-  // the memory's either way.  An empty block is left to k_update_multi (out of place it still carries the tableau over).
+  // the memory's either way.  An empty block is 32 identities: out of place that carries the tableau over.
   const int np = ring_count(ring, K, kmax, &sh_np);
-  if (np == 0) return;
+  if (np == 0 && !OOP) return;
   const int strip = blockIdx.x % nstrips_full;
   const int grp = blockIdx.x / nstrips_full;
   const int cj = strip * 512 + 2 * threadIdx.x;
@@ -2701,8 +2702,8 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     }
     int rows = choose_sweep_rows(m_local, B.ld, 32, cus);
     while (rows > kSweepChunk && (int64_t)rows * B.ld * 8 >= (int64_t)1 << 32) rows -= kSweepChunk;
-    launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, pipe ? 64 : 0, 0);
-    launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, pipe ? 64 : 0, 32);
+    launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, pipe ? 65 : 0, 0);
+    launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, pipe ? 65 : 0, 32);
     rows_per_wg = pipe ? rows64 : rows;
 #ifndef LPX_STEADY_PARTIAL
 #define LPX_STEADY_PARTIAL 1
@@ -2737,7 +2738,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
         while (rows48 > 4 && (int64_t)rows48 * B.ld * 8 >= (int64_t)1 << 32) rows48 -= 4;   // 32-bit offsets
       }
       launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
-      launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);
+      if (B.ld % 512 != 0) launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);   // the partial last strip
       rows_per_wg = rows48;   // (what lpx_state_get_info reports: the kernel that did the work)
     } else
 #endif
