@@ -392,7 +392,9 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
   // Decisions one block ahead of the sweeps, as on one GPU (lpx_engine.cpp blocked_loop_overlapped): every shard
   // keeps two tableau buffers; the decision kernels of block k read the buffers sweep k-1 reads (its pivots are
   // pending ones for them, like their own) and run beside it on their own streams.
-  if (M->sh[0]->opt[LPX_OPT_OVERLAP] != 0) {
+  // (a budget that fits one block has nothing to run beside: the serial form, as in lpx_engine.cpp blocked_loop)
+  const bool one_block = max_pivots >= 0 && max_pivots + 1 <= K;
+  if (M->sh[0]->opt[LPX_OPT_OVERLAP] != 0 && !one_block) {
     bool ok = true;
     for (int r = 0; r < G && ok; r++) {
       HIP_TRY(hipSetDevice(M->device[r]));
