@@ -134,7 +134,8 @@ typedef enum lpx_option {
   LPX_OPT_UPDATE_U = 11,      /* one-pass update: 16-byte accesses per thread per row (1, 2, 4)                      */
   LPX_OPT_UPDATE_ROWS = 12,   /* one-pass update: rows per workgroup (even, 2..256)                                  */
   LPX_OPT_A2_OFFSET = 13,     /* skew between the two tableau buffers in doubles (before the second one exists)      */
-  LPX_OPT_COUNT = 14
+  LPX_OPT_SWEEP_FORM = 14,    /* blocks of 17..32: 0 = k_sweep32_pull (LDS-DMA staging, batches pulled in address order; default), 1 = k_sweep32_steady (register staging, runs of rows), 2 = k_sweep32_dma (LDS-DMA, runs) */
+  LPX_OPT_COUNT = 15
 } lpx_option;
 int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value);
 int lpx_state_get_option(const lpx_state* s, int32_t key, int64_t* value);
@@ -153,9 +154,11 @@ typedef struct lpx_state_info {
   int32_t overlapped;           /* 1: the last blocked loop ran decisions beside sweeps (two tableau buffers)      */
   int32_t nontemporal;          /* tableau accesses are non-temporal                                               */
   int32_t sweep_rows;           /* rows per workgroup (run length) of the last blocked sweep                       */
-  int32_t reserved;
+  int32_t sweep_kernel;         /* the kernel that swept the bulk of the tableau last (lpx_sweep_kernel_name)      */
 } lpx_state_info;
 int lpx_state_get_info(lpx_state* s, lpx_state_info* out);
+/* Name of a lpx_state_info.sweep_kernel code as rocprofv3 prints it ("k_sweep32_dma", "k_update_tiles", ...; "" = none). */
+const char* lpx_sweep_kernel_name(int32_t code);
 /* Phase timestamps of the last decision launch (LPX_OPT_CHAIN_TRACE = 1): 5 ticks (100 MHz) per decision —
  * start, phase A done, barrier passed, phase B done, next entering slot known.  ticks has room for 5 * cap
  * values; *ndecisions = decisions of the last launch that are present. */

@@ -74,6 +74,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_U", 1, 1, 4},                     // LPX_OPT_UPDATE_U
     {"LPX_ROWS_PER_TILE", 2, 2, 256},       // LPX_OPT_UPDATE_ROWS
     {"LPX_A2_OFFSET", 512, 0, 1 << 20},     // LPX_OPT_A2_OFFSET
+    {"LPX_SWEEP_FORM", 0, 0, 2},            // LPX_OPT_SWEEP_FORM
 };
 
 static const int64_t* env_defaults() {
@@ -166,6 +167,9 @@ void free_state(lpx_state* s) {
   (void)hipFree(s->R.chain_own_b);
   (void)hipFree(s->R.chain_dbg);
   (void)hipFree(s->R.census);
+  (void)hipFree(const_cast<double*>(s->R.zeros));
+  (void)hipFree(s->R.tickets);
+  (void)hipFree(s->R.col_packed);
   (void)hipFree(s->R.mg_mail);
   (void)hipFree(s->R.mg_arrive);
   (void)hipFree(s->d_cand);
@@ -501,6 +505,14 @@ int ensure_block_ring(lpx_state* s) {
   HIP_TRY(hipMemsetAsync(s->R.chain_dbg, 0, 5 * lpxk::kBlockMax * sizeof(long long), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.census, (lpxk::kChainMaxWgs + 2 + 1200) * sizeof(unsigned)));   // + room for diagnostic builds
   HIP_TRY(hipMemsetAsync(s->R.census, 0, (lpxk::kChainMaxWgs + 2 + 1200) * sizeof(unsigned), s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.zeros, 256));
+  HIP_TRY(hipMemsetAsync(const_cast<double*>(s->R.zeros), 0, 256, s->stream));
+  // k_sweep32_pull: a ticket counter per 128-column sub-strip (128 bytes apart) and the block's multipliers packed by
+  // batches of 4 rows (1 KiB each)
+  HIP_TRY(hipMalloc((void**)&s->R.tickets, (size_t)(s->B.ld / 128 + 4) * 128));
+  HIP_TRY(hipMemsetAsync(s->R.tickets, 0, (size_t)(s->B.ld / 128 + 4) * 128, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.col_packed, (size_t)(mp / 4 + 1) * 1024));
+  HIP_TRY(hipMemsetAsync(s->R.col_packed, 0, (size_t)(mp / 4 + 1) * 1024, s->stream));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));
@@ -595,9 +607,12 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
   }
   // CUs the sweep's stream may use: all but the decisions' reserved ones on the masked overlap stream
   const int cus = (stream == s->ov_sweep && s->ov_masked) ? device_cus(s) - s->ov_chain_cus : device_cus(s);
+  int kernel_used = 0;
   s->info.sweep_rows = lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, (int)s->opt[LPX_OPT_SWEEP_ROWS],
                                                 s->nontemporal, stream, A_src, b_src,
-                                                sample ? s->ev[s->ev_used + 1] : nullptr, cus);
+                                                sample ? s->ev[s->ev_used + 1] : nullptr, cus,
+                                                (int)s->opt[LPX_OPT_SWEEP_FORM], &kernel_used);
+  s->info.sweep_kernel = kernel_used;
   if (sample) s->ev_used += 2;
   HIP_TRY(hipGetLastError());
   return 0;
@@ -905,6 +920,8 @@ extern "C" int lpx_state_get_info(lpx_state* s, lpx_state_info* out) {
   *out = s->info;
   return 0;
 }
+
+extern "C" const char* lpx_sweep_kernel_name(int32_t code) { return lpxk::sweep_kernel_name(code); }
 
 // diagnostic builds (LPX_SWEEP_STAMPS): raw copy of the census buffer behind the sweep's sample word
 extern "C" int lpx_debug_read_census(lpx_state* s, uint32_t* out, int32_t count) {

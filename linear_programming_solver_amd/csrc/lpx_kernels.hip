@@ -2031,6 +2031,444 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ 
   }
 }
 
+// ---- the steady state of the sweep with the tableau staged through LDS by LDS-DMA (round 3) -------------------------
+// Same work split and arithmetic as k_sweep32_steady; what changes is where a batch waits for the fp64 pipe.  There a
+// wave parks its in-flight batches in registers (3 x 16 VGPRs on top of the 128 that hold the pivot-row slices: two
+// batches in flight is all the register file allows, and two batches = ~4 us of a SIMD's arithmetic is less than the
+// ~5 us the memory system takes under this load).  Here a wave issues global_load_lds_dwordx4 (1 KiB per instruction,
+// lane t's 16 bytes land at slot + 16 t) into a ring of NS slots of its OWN in LDS and reads its batch back with one
+// ds_read_b128 per row when the batch's turn comes: NS batches in flight per wave, no register parked, and the
+// destination of a hand-issued load is LDS, not a VGPR — the compiler has nothing to copy, spill or reuse before the
+// data has landed (the hazard class of k_sweep32_steady's register loads).  What stays hand-counted is
+// vmcnt: the DMA is invisible to the compiler's own bookkeeping, so every read-back sits behind an asm wait with a
+// memory clobber.  vmcnt counts this wave's loads, stores and LDS-DMAs in issue order, and "at most N outstanding"
+// completes every operation that has at least N younger ones: operations the compiler adds only lengthen a wait; a
+// wait is too short only if FEWER operations follow than assumed, which is what the tail counts below are for.
+//
+// LDS (80 KiB, two workgroups per CU): multipliers [2 chunks][32 pivots][32 rows] = 16 KiB, filled by LDS-DMA too
+// (one piece = 4 pivots x 32 rows; each wave brings two pieces of the NEXT chunk right after the chunk barrier), then
+// 4 waves x NS slots x 4 KiB.  No slot is shared between waves: the only workgroup barrier is the one per chunk that
+// publishes the next chunk's multipliers.
+constexpr int kDmaK = 32, kDmaRB = 4, kDmaCH = 32;
+#ifndef LPX_DMA_NS
+#define LPX_DMA_NS 4
+#endif
+#ifndef LPX_DMA_DIAG
+#define LPX_DMA_DIAG 0   // 1, 2: diagnostic builds of scripts/micro/sweep_dma.hip only (memory pass alone / arithmetic alone)
+#endif
+constexpr int kDmaNS = LPX_DMA_NS;
+constexpr int kDmaMultBytes = 2 * kDmaK * kDmaCH * 8;
+constexpr int kDmaSlotBytes = kDmaRB * 64 * 16;
+constexpr int kDmaLdsBytes = kDmaMultBytes + 4 * kDmaNS * kDmaSlotBytes;
+static_assert(2 * kDmaLdsBytes <= 160 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(p);
+}
+// One batch: RB = 4 rows of this wave's 1 KiB each -> LDS at lds, lds + 1 KiB, ...  The leading lgkmcnt(0) retires the
+// wave's own ds_reads of the slot being refilled (M0, the LDS base of an LDS-DMA, is written in the statement that uses
+// it and restored: the compiler reserves it).
+template <bool NT>
+__device__ __forceinline__ void dma_batch4(const char* base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+                                           uint32_t lds) {
+  unsigned keep;
+  if (NT)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %4, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %5, %1 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds) : "memory", "scc");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %4, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %5, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds) : "memory", "scc");
+}
+// two 1 KiB pieces from per-lane addresses (the multipliers: L2-resident, default cache policy)
+__device__ __forceinline__ void dma_pieces2(const double* p0, const double* p1, uint32_t lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(p0), "v"(p1), "s"(lds) : "memory", "scc");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// sweep_apply's steady-state form over a linear multiplier image: element (s, row) at mrow[s * STRIDE + row]
+template <int K, int RB, int STRIDE>
+__device__ __forceinline__ void sweep_apply_lin(d2 (&x)[RB], const d2 (&pr)[K], const double* mrow) {
+  constexpr int D = 2;
+  d2 cc[D + 1][RB / 2];
+#pragma unroll
+  for (int s = 0; s < D && s < K; ++s)
+#pragma unroll
+    for (int r = 0; r < RB; r += 2) cc[s][r / 2] = *reinterpret_cast<const d2*>(mrow + s * STRIDE + r);
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    if (s + D < K) {
+#pragma unroll
+      for (int r = 0; r < RB; r += 2)
+        cc[(s + D) % (D + 1)][r / 2] = *reinterpret_cast<const d2*>(mrow + (s + D) * STRIDE + r);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < RB; r += 2) {
+      const d2 c2 = cc[s % (D + 1)][r / 2];
+      x[r].x = __dsub_rn(x[r].x, __dmul_rn(c2.x, pr[s].x));                      // LPState.java:162
+      x[r].y = __dsub_rn(x[r].y, __dmul_rn(c2.x, pr[s].y));
+      x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(c2.y, pr[s].x));
+      x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(c2.y, pr[s].y));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <bool NT, bool OOP>
+__global__ __launch_bounds__(256, 2) void k_sweep32_dma(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                        int64_t ld, int m_local,
+                                                        const double* __restrict__ prow_ring,
+                                                        const double* __restrict__ col_ring, int64_t mp,
+                                                        const LpxCtl* __restrict__ ring, int kmax, int cstart,
+                                                        int cstep, int nstrips_full,
+                                                        const double* __restrict__ zeros, int xcd_remap) {
+  // Which rows a workgroup takes.  The tableau's rows go in chunks of CH = 32 (8 batches of RB = 4: the unit the
+  // multipliers are staged in); workgroup (strip, g) takes the chunks g * cstart + c * cstep, c = 0, 1, ...:
+  //   cstep == 1: a contiguous run of cstart chunks (the split of k_sweep32_steady: several rounds of workgroups);
+  //   cstep == G, cstart == 1 (G = workgroups per strip): every G-th chunk.  With the whole grid resident (G x strips =
+  //   two workgroups per CU) all workgroups walk down the tableau together, what the chip has in flight is one window
+  //   of G x 32 whole rows, and the pivot-row slices and the prologue are paid once per sweep instead of once per run.
+  constexpr int K = kDmaK, RB = kDmaRB, NS = kDmaNS, CH = kDmaCH, BPC = CH / RB;
+  // every batch: RB LDS-DMAs + RB stores.  Behind the DMAs of batch bt, when its turn comes: the stores of batch
+  // bt - NS, then DMAs + stores of NS - 1 batches
+  constexpr int kAhead = 2 * RB * NS - RB;
+  static_assert(kAhead <= 60, "vmcnt is six bits wide");
+  __shared__ __attribute__((aligned(16))) char sm[kDmaLdsBytes];   // ONE LDS object (a second one beside LDS-DMA
+                                                                    // staging makes hipcc drain vmcnt before ds_reads)
+  // A partly filled block runs the same straight-line code with identity steps, as in k_sweep32_steady: multiplier +0
+  // (the DMA of a slot >= np reads the zero page) AND pivot-row slice +0, x - (+0 * +0) = x bit for bit.
+  const int np = ring_count(ring, K, kmax, reinterpret_cast<int*>(sm));
+  __syncthreads();   // everyone has read the count before a DMA lands on it
+  if (np == 0 && !OOP) return;
+  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the XCD's share, MI355X_MICROARCH.md).  With
+  // strip = blockIdx % nstrips an XCD would only ever touch the strips s = x (mod 8), i.e. — the row pitch being a
+  // multiple of the HBM channel interleave — one eighth of the memory channels.  xcd_remap: an XCD takes ALL strips
+  // of every 8th row group instead (and needs only its own groups' multipliers in its L2).
+  int strip, grp;
+  if (xcd_remap) {
+    const int j = blockIdx.x >> 3;
+    strip = j % nstrips_full;
+    grp = (j / nstrips_full) * 8 + (blockIdx.x & 7);
+  } else {
+    strip = blockIdx.x % nstrips_full;
+    grp = blockIdx.x / nstrips_full;
+  }
+  const int cj = strip * 512 + 2 * threadIdx.x;
+  const int nbt = m_local / RB;                       // batches of the whole tableau (m_local % RB == 0: launcher)
+  const int nct = (nbt + BPC - 1) / BPC;              // chunks of the whole tableau (the last one may be partial)
+  const int c0 = grp * cstart;
+  // the workgroup's chunks and batches (only the tableau's last chunk can be short, and only its last owner has it)
+  const int nc = cstep == 1 ? max(0, min(cstart, nct - c0)) : (nct > c0 && grp < cstep ? (nct - c0 + cstep - 1) / cstep : 0);
+  const int last_chunk = c0 + (nc - 1) * cstep;
+  const int nb = nc <= 0 ? 0 : (nc - 1) * BPC + min(BPC, nbt - last_chunk * BPC);
+  if (nb <= 0) return;
+  const int64_t row_bytes = ld * 8;
+  const int64_t batch_bytes = RB * row_bytes;
+  char* const dst_base = reinterpret_cast<char*>(A + strip * 512);
+  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + strip * 512) : dst_base;
+  const uint32_t off0 = threadIdx.x * 16u;
+  const uint32_t rb32 = (uint32_t)row_bytes;          // 3 rows x ld x 8 < 2^32 (launcher)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t lds_mult = lds_addr_of(sm);
+  char* const stage = sm + kDmaMultBytes + wave * (NS * kDmaSlotBytes);
+  const uint32_t lds_stage = lds_addr_of(stage);
+  const int nchunks = (nb + BPC - 1) / BPC;
+
+  // multipliers of the workgroup's chunk ch -> its half of the image [pivot][row in chunk]; this wave's two pieces (4
+  // pivots x 32 rows each); a lane brings two rows
+  auto mult_dma = [&](int ch) {
+    const int r = (lane & 15) * 2;
+    const int64_t row = ((int64_t)c0 + (int64_t)ch * cstep) * CH + r;
+    const bool in_rows = ch * BPC + (r >> 2) < nb;    // (rows come in fours)
+    const double* src[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int s = (2 * wave + p) * 4 + (lane >> 4);
+      src[p] = (s < np && in_rows) ? col_ring + ((int64_t)s * mp + row) : zeros;
+    }
+    dma_pieces2(src[0], src[1], (uint32_t)__builtin_amdgcn_readfirstlane(
+                                    (int)(lds_mult + (uint32_t)((ch & 1) * (K * CH * 8) + 2 * wave * 1024))));
+  };
+  // first byte of the workgroup's batch bt, relative to the strip's first row
+  auto batch_off = [&](int bt) -> int64_t {
+    return (((int64_t)c0 + (int64_t)(bt / BPC) * cstep) * BPC + bt % BPC) * batch_bytes;
+  };
+  auto batch_dma = [&](int bt) {   // the workgroup's batch bt -> slot bt % NS
+#if LPX_DMA_DIAG == 2
+    if (bt >= NS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
+#endif
+    const char* const base = src_base + batch_off(bt);   // uniform
+    dma_batch4<NT>(base, off0, off0 + rb32, off0 + 2 * rb32, off0 + 3 * rb32,
+                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_stage + (uint32_t)((bt % NS) * kDmaSlotBytes))));
+  };
+
+  // prologue: chunk 0's multipliers, the first NS batches, the thread's 32 pivot-row slices; everything is waited for
+  mult_dma(0);
+#pragma unroll
+  for (int u = 0; u < NS; ++u)
+    if (u < nb) batch_dma(u);   // uniform
+  d2 pr[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj);
+    if (s >= np) pr[s] = d2{0.0, 0.0};   // uniform
+  }
+  dma_wait<0>();
+  asm volatile("s_barrier" ::: "memory");
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const bool more = ch + 1 < nchunks;   // then this chunk is a full one: BPC batches
+    if (more) mult_dma(ch + 1);           // into the half every wave has left (the barrier at the end of chunk ch - 1)
+    const double* const mhalf = reinterpret_cast<const double*>(sm) + (ch & 1) * (K * CH);
+    const int b_lo = ch * BPC, b_hi = min(nb, b_lo + BPC);
+#pragma unroll 1
+    for (int bt = b_lo; bt < b_hi; ++bt) {
+      // this batch's DMAs have landed once at most kAhead younger operations are outstanding; at the end of the run
+      // fewer follow: RB per batch that is still to come (their stores), plus the RB * NS stores in between
+      const int rem = nb - 1 - bt;
+      if (rem >= NS - 1) dma_wait<kAhead>();
+      else if (rem == 2) dma_wait<(NS >= 3 ? RB * NS + 2 * RB : 0)>();
+      else if (rem == 1) dma_wait<(NS >= 2 ? RB * NS + RB : 0)>();
+      else dma_wait<RB * NS>();
+      const char* const slot = stage + (bt % NS) * kDmaSlotBytes + lane * 16;
+      d2 x[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) x[r] = *reinterpret_cast<const d2*>(slot + r * 1024);
+      if (bt + NS < nb) batch_dma(bt + NS);   // refill the slot just read (the statement waits for the reads first)
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if LPX_DMA_DIAG != 1   // (diagnostic build 1: the memory pass alone — every batch through LDS, no arithmetic)
+      sweep_apply_lin<K, RB, CH>(x, pr, mhalf + (bt - b_lo) * RB);
+#endif
+      char* const out = dst_base + batch_off(bt);   // uniform
+#if LPX_DMA_DIAG == 2   // (diagnostic build 2: the arithmetic alone — one batch read, nothing stored)
+      if (x[0].x == 1.2345e300)
+#endif
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        d2* q = reinterpret_cast<d2*>(out + (off0 + (uint32_t)r * rb32));
+        if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
+      }
+    }
+    if (more) {
+      dma_wait<RB * BPC - RB>();   // the next chunk's pieces were issued before this chunk's BPC x RB stores
+      asm volatile("s_barrier" ::: "memory");
+    }
+  }
+}
+
+// ---- the steady state of the sweep, every wave on its own, batches PULLED in address order (round 3) ----------------
+// What bounds k_sweep32_dma is its memory pass: on the same GPU a one-shot copy of the tableau in 4-row x 512-column
+// tiles dispatched in address order streams at 6.1 TB/s, the same tiles copied by persistent workgroups that walk
+// down their strips at 5.0-5.4 (runs of rows, every G-th tile, any depth of prefetch), and persistent workgroups that
+// PULL their next tile from a per-strip counter at 6.0-6.2 (scripts/micro/copy_patterns.hip,
+// profiles/r03_copy_patterns.txt): what the hardware dispatcher gives one-shot workgroups for free is that tiles
+// are handed out in address order to whoever is free, so the rows in flight chip-wide stay one dense, moving window
+// (DRAM pages are used up while they are open); statically assigned rows drift apart.
+// So here a WAVE is the worker: it is bound to a 128-column sub-strip (its 32 pivot-row slices stay in registers, as
+// before) and takes the next 4-row batch of that sub-strip from the sub-strip's ticket counter.  A batch brings its
+// own multipliers (32 pivots x 4 rows = 1 KiB = one LDS-DMA, per-lane source addresses), so nothing is shared between
+// the waves of a workgroup: no barrier, no chunk, no run length, no rounds of workgroups, no tail — the grid is
+// simply what is resident, and a slow CU pulls fewer tickets.
+// Per wave and iteration i (one batch each), everything LDS-DMA / hand-counted as in k_sweep32_dma:
+//   wait vmcnt(24)   -> what iteration i-3 issued has landed: the rows and multipliers of batch i, the ticket t(i+3)
+//   read batch i from stage slot i % 3 (ds_read_b128 x 4)
+//   issue: 4 LDS-DMAs of batch t(i+3) into that slot, 1 LDS-DMA of its multipliers into slot (i+3) % 4, 1 ticket atomic
+//   32 steps on batch i, multipliers from slot i % 4;  4 stores
+// i.e. 10 operations per iteration, and behind the youngest operation of iteration i-3 that must be complete (its
+// atomic) come its 4 stores and 2 x 10: 24.  Whenever one of the last three iterations issued less (start, end of the
+// tickets) the wait is vmcnt(0).  The ticket's destination is a VGPR of a hand-issued atomic: it is handed to the
+// compiler behind the wait and a scheduling barrier, the same two-statement form as strip_wait4.
+constexpr int kPullNS = 3, kPullNM = 4;
+constexpr int kPullWaveBytes = kPullNS * kDmaSlotBytes + kPullNM * 1024;   // 16 KiB per wave
+static_assert(8 * kPullWaveBytes <= 160 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ void dma_piece1(const double* p, uint32_t lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(p), "s"(lds) : "memory");
+}
+// one returning atomic add by lane 0 (EXEC is all ones at every call site)
+__device__ __forceinline__ void ticket_pull(unsigned& tk, unsigned* ctr) {
+  const unsigned zero = 0, one = 1;
+  asm volatile("s_mov_b64 exec, 1\n\ts_nop 0\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1"
+               : "=v"(tk) : "v"(zero), "v"(one), "s"(ctr) : "memory");
+}
+__device__ __forceinline__ int ticket_take(unsigned& tk) {   // behind a wait that covers the atomic
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" : "+v"(tk) :: "memory");
+  return __builtin_amdgcn_readfirstlane((int)tk);
+}
+
+// The multipliers as the pulled batches want them: colT[batch][pivot][row in batch], 1 KiB per batch — ONE contiguous
+// LDS-DMA piece, where the ring's [pivot][row] layout makes a batch's multipliers 32 pieces of 32 bytes on 32 different
+// lines (measured: the sweep of a block whose multipliers all come from one line ran 9 % faster than a real one).  The
+// identity steps of a partly filled block (pivot >= np) get +0 here.  8 MiB at cfg4, a few microseconds in front of the
+// sweep on its stream.
+__global__ __launch_bounds__(256) void k_pack_multipliers(const double* __restrict__ col_ring, int64_t mp,
+                                                          const LpxCtl* __restrict__ ring, int kmax, int nbt,
+                                                          double* __restrict__ colT) {
+  __shared__ int sh_np;
+  const int np = ring_count(ring, kDmaK, kmax, &sh_np);
+  const int s = threadIdx.x & 31;
+  const int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (b >= nbt) return;
+  d2 lo = d2{0.0, 0.0}, hi = d2{0.0, 0.0};
+  if (s < np) {
+    const d2* p = reinterpret_cast<const d2*>(col_ring + (int64_t)s * mp + b * 4);   // mp is even: 16-byte aligned
+    lo = p[0];
+    hi = p[1];
+  }
+  d2* q = reinterpret_cast<d2*>(colT + b * 128 + s * 4);
+  q[0] = lo;
+  q[1] = hi;
+}
+
+// one batch: RB = 4 rows (1 KiB each for this wave) and the batch's 1 KiB of packed multipliers
+template <bool NT>
+__device__ __forceinline__ void dma_batch4m(const char* base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+                                            uint32_t lds, const char* mbase, uint32_t lds_m) {
+  unsigned keep;
+  if (NT)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %4, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %5, %1 nt\n\ts_mov_b32 m0, %8\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %7\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds), "s"(mbase), "s"(lds_m)
+                 : "memory", "scc");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %4, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %5, %1\n\ts_mov_b32 m0, %8\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %7\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds), "s"(mbase), "s"(lds_m)
+                 : "memory", "scc");
+}
+
+template <bool NT, bool OOP>
+__global__ __launch_bounds__(256, 2) void k_sweep32_pull(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                         int64_t ld, int m_local,
+                                                         const double* __restrict__ prow_ring,
+                                                         const double* __restrict__ col_ring, int64_t mp,
+                                                         const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
+                                                         const double* __restrict__ col_packed,
+                                                         unsigned* __restrict__ tickets) {
+  constexpr int K = kDmaK, RB = kDmaRB, NS = kPullNS, NM = kPullNM;
+  constexpr int kOps = 2 * RB + 2;                 // per iteration: RB row DMAs, 1 multiplier DMA, 1 atomic, RB stores
+  constexpr int kAhead = RB + (NS - 1) * kOps;     // younger than the atomic of iteration i - NS at iteration i's wait
+  static_assert(kAhead <= 60, "vmcnt is six bits wide");
+  __shared__ __attribute__((aligned(16))) char sm[4 * kPullWaveBytes];
+  const int np = ring_count(ring, K, kmax, reinterpret_cast<int*>(sm));
+  __syncthreads();   // everyone has read the count before a DMA lands on it
+  if (np == 0 && !OOP) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // The grid is G workgroups per strip.  blockIdx % 8 names the XCD's share of the grid; with strip = blockIdx % nstrips
+  // an XCD would only see the strips s = x (mod 8), i.e. one eighth of the memory channels (the row pitch is a multiple
+  // of the channel interleave).  Shifting each XCD's walk over the strips by x * nstrips / 8 gives every XCD all
+  // strips and still every strip G workgroups.
+  const int strip = (nstrips_full % 8 == 0)
+                        ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(nstrips_full / 8)) % (unsigned)nstrips_full)
+                        : (int)(blockIdx.x % (unsigned)nstrips_full);
+  const int sub = strip * 4 + wave;
+  const int nbt = m_local / RB;                    // batches of the tableau (m_local % RB == 0: launcher)
+  unsigned* const ctr = tickets + sub * 32;        // one counter per sub-strip, 128 bytes apart
+  const int64_t row_bytes = ld * 8;
+  const int64_t batch_bytes = RB * row_bytes;
+  char* const dst_base = reinterpret_cast<char*>(A + sub * 128);
+  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + sub * 128) : dst_base;
+  const uint32_t off0 = lane * 16u;
+  const uint32_t rb32 = (uint32_t)row_bytes;       // 3 rows x ld x 8 < 2^32 (launcher)
+  char* const stage = sm + wave * kPullWaveBytes;
+  char* const mult = stage + NS * kDmaSlotBytes;
+  const uint32_t lds_stage = lds_addr_of(stage), lds_mult = lds_addr_of(mult);
+  auto issue = [&](int t, int it) {   // batch t becomes iteration it's: rows -> stage slot it % NS, multipliers -> it % NM
+    const char* const base = src_base + (int64_t)t * batch_bytes;                                     // uniform
+    const char* const mbase = reinterpret_cast<const char*>(col_packed) + (int64_t)t * 1024;          // uniform
+    dma_batch4m<NT>(base, off0, off0 + rb32, off0 + 2 * rb32, off0 + 3 * rb32,
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_stage + (uint32_t)((it % NS) * kDmaSlotBytes))),
+                    mbase, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_mult + (uint32_t)((it % NM) * 1024))));
+  };
+
+  // prologue: tickets of iterations 0 .. NS-1, their DMAs, the tickets of iterations NS .. 2 NS - 1 (pending), the
+  // thread's 32 pivot-row slices; everything is waited for
+  unsigned tk[NS];
+  int bq[NS + 1];   // bq[k]: the batch of iteration i + k (>= nbt: none)
+#pragma unroll
+  for (int u = 0; u < NS; ++u) ticket_pull(tk[u], ctr);
+  dma_wait<0>();
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    bq[u] = ticket_take(tk[u]);
+    if (bq[u] < nbt) issue(bq[u], u);   // uniform
+  }
+#pragma unroll
+  for (int u = 0; u < NS; ++u) ticket_pull(tk[u], ctr);
+  d2 pr[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + sub * 128 + 2 * lane);
+    if (s >= np) pr[s] = d2{0.0, 0.0};   // uniform
+  }
+  dma_wait<0>();
+
+  int full = 0;   // consecutive most recent iterations that issued all kOps operations
+#pragma unroll 1
+  for (int i0 = 0;; i0 += NS) {
+    if (bq[0] >= nbt) break;   // tickets only grow: nothing is left for this wave (its pending pulls are waited for below)
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int i = i0 + u;
+      const int t = bq[0];
+      if (t < nbt) {   // uniform
+        // (the first NS iterations need what the prologue issued and waited for)
+        if (full >= NS) dma_wait<kAhead>(); else if (i >= NS) dma_wait<0>();
+        bq[NS] = ticket_take(tk[u]);   // pulled at iteration i - NS: the batch of iteration i + NS
+        const char* const slot = stage + u * kDmaSlotBytes + lane * 16;
+        d2 x[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) x[r] = *reinterpret_cast<const d2*>(slot + r * 1024);
+        const bool more = bq[NS] < nbt;
+        if (more) issue(bq[NS], i + NS);   // refills the slot just read (the statement waits for the reads first)
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ticket_pull(tk[u], ctr);
+        full = more ? full + 1 : 0;
+#if LPX_DMA_DIAG != 1   // (diagnostic build 1: the memory pass alone)
+        sweep_apply_lin<K, RB, RB>(x, pr, reinterpret_cast<const double*>(mult + (i % NM) * 1024));
+#endif
+        char* const out = dst_base + (int64_t)t * batch_bytes;   // uniform
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          d2* q = reinterpret_cast<d2*>(out + (off0 + (uint32_t)r * rb32));
+          if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
+        }
+      } else {
+        bq[NS] = INT_MAX;   // (tickets only grow: what this wave still has pending names nothing either)
+      }
+#pragma unroll
+      for (int k = 0; k < NS; ++k) bq[k] = bq[k + 1];
+    }
+  }
+  dma_wait<0>();   // the pending ticket atomics write registers of this wave: let them land before it ends
+}
+
 // ---- 64 pivots per pass: two stages of 32 inside one workgroup ------------------------------------------------------
 // At K = 32 the sweep is bound by memory (16 m n bytes per pass at ~5 TB/s), not by the 2 m n K unfused fp64
 // operations; twice the pivots per pass halves the bytes per pivot.  A thread cannot hold 64 pivot-row slices (256
@@ -2530,8 +2968,19 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
   hipLaunchKernelGGL((k_sweep32_steady<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 48, 1);
 #define LPX_PRE_PIPE(NT_, OOP_) \
   hipLaunchKernelGGL((k_sweep64_pipe<NT_, OOP_>), dim3(1), dim3(512), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 48, 1);
+#define LPX_PRE_DMA(NT_, OOP_) \
+  hipLaunchKernelGGL((k_sweep32_dma<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 2, 1, 1, R.zeros, 0);
   LPX_EACH_NT_OOP(LPX_PRE_T2) LPX_EACH_NT_OOP(LPX_PRE_T4) LPX_EACH_NT_OOP(LPX_PRE_T8) LPX_EACH_NT_OOP(LPX_PRE_T16)
   LPX_EACH_NT_OOP(LPX_PRE_T32) LPX_EACH_NT_OOP(LPX_PRE_MULTI) LPX_EACH_NT_OOP(LPX_PRE_STEADY) LPX_EACH_NT_OOP(LPX_PRE_PIPE)
+  LPX_EACH_NT_OOP(LPX_PRE_DMA)
+#define LPX_PRE_PULL(NT_, OOP_) \
+  hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 1, R.col_packed, R.tickets);
+  if (R.tickets && R.col_packed) {   // m_local = 0: the first ticket already names nothing
+    LPX_EACH_NT_OOP(LPX_PRE_PULL)
+    hipLaunchKernelGGL(k_pack_multipliers, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed);
+  }
+#undef LPX_PRE_PULL
+#undef LPX_PRE_DMA
 #undef LPX_PRE_PIPE
 #undef LPX_PRE_STEADY
 #undef LPX_PRE_MULTI
@@ -2607,6 +3056,51 @@ static void launch_sweep_steady(const Buffers& B, const BlockRing& R, int m_loca
 #undef LPX_LAUNCH_STEADY
 }
 
+// the LDS-DMA form of the same kernel (round 3).  rows_per_wg > 0: contiguous runs of that many rows, as
+// k_sweep32_steady; rows_per_wg <= 0: every G-th batch of 4 rows, G = workgroups per strip chosen so that the whole
+// grid is resident at once (`slots` = two workgroups per CU the stream may use) — see the kernel.
+static void launch_sweep_dma(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
+                             const double* A_src, hipStream_t s, int slots = 512, int xcd_remap = 1) {
+  const int nstrips_full = (int)(B.ld / 512);
+  const int nct = (m_local / 4 + 7) / 8;   // chunks of 32 rows
+  int ngroups, cstart, cstep;
+  if (rows_per_wg > 0) {
+    cstart = std::max(1, (rows_per_wg + 31) / 32);
+    cstep = 1;
+    ngroups = (nct + cstart - 1) / cstart;
+  } else {
+    ngroups = std::max(1, std::min(nct, slots / std::max(1, nstrips_full)));
+    cstart = 1;
+    cstep = ngroups;
+  }
+  const int groups_launched = xcd_remap ? (ngroups + 7) / 8 * 8 : ngroups;   // (surplus workgroups return at once)
+  const dim3 grid(nstrips_full * groups_launched), block(256);
+#define LPX_LAUNCH_DMA(NT_, OOP_)                                                                                \
+  hipLaunchKernelGGL((k_sweep32_dma<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
+                     R.up, kmax, cstart, cstep, nstrips_full, R.zeros, xcd_remap)
+  if (A_src) { if (nt) LPX_LAUNCH_DMA(true, true); else LPX_LAUNCH_DMA(false, true); }
+  else { if (nt) LPX_LAUNCH_DMA(true, false); else LPX_LAUNCH_DMA(false, false); }
+#undef LPX_LAUNCH_DMA
+}
+
+// every wave on its own, batches pulled from per-sub-strip ticket counters (R.tickets: zeroed here, on the stream);
+// the grid is what is resident: G workgroups per strip, G x strips <= slots (two workgroups per CU the stream may use)
+static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
+                              hipStream_t s, int slots = 512) {
+  const int nstrips_full = (int)(B.ld / 512);
+  const int nbt = m_local / 4;
+  const int G = std::max(1, std::min(nbt, slots / std::max(1, nstrips_full)));
+  (void)hipMemsetAsync(R.tickets, 0, (size_t)nstrips_full * 4 * 128, s);
+  hipLaunchKernelGGL(k_pack_multipliers, dim3((nbt + 7) / 8), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed);
+  const dim3 grid(nstrips_full * G), block(256);
+#define LPX_LAUNCH_PULL(NT_, OOP_)                                                                                \
+  hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
+                     R.up, kmax, nstrips_full, R.col_packed, R.tickets)
+  if (A_src) { if (nt) LPX_LAUNCH_PULL(true, true); else LPX_LAUNCH_PULL(false, true); }
+  else { if (nt) LPX_LAUNCH_PULL(true, false); else LPX_LAUNCH_PULL(false, false); }
+#undef LPX_LAUNCH_PULL
+}
+
 static void launch_sweep64_pipe(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
                                 const double* A_src, hipStream_t s) {
   const int nstrips_full = (int)(B.ld / 512);
@@ -2667,9 +3161,23 @@ static int choose_pipe_rows(int m_local, int nstrips_full, int slots, int prolog
 }
 
 // rows_per_wg <= 0: chosen here (see choose_sweep_rows); cus: CUs the stream may use (0: the whole device)
+const char* sweep_kernel_name(int code) {
+  switch (code) {
+    case kSweepTiles: return "k_update_tiles";
+    case kSweepMulti: return "k_update_multi";
+    case kSweepSteady: return "k_sweep32_steady";
+    case kSweepPipe64: return "k_sweep64_pipe";
+    case kSweepDma: return "k_sweep32_dma";
+    case kSweepPull: return "k_sweep32_pull";
+    default: return "";
+  }
+}
+
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep,
-                       int cus) {
+                       int cus, int form, int* kernel_used) {
+  int used = kSweepNone;
+  if (kernel_used) *kernel_used = used;
   if (K < 1) return 0;
   if (cus <= 0) {
     int dev = 0;
@@ -2687,6 +3195,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     else if (K <= 8) launch_sweep_tiles<8>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
     else launch_sweep_tiles<16>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
     rows_per_wg = rows_per_tile;
+    used = kSweepTiles;
   } else if (K > 32) {
     // blocks of up to 64 pivots.  A full block of 64 over the full strips goes through the two-stage kernel in one
     // pass; whatever that leaves (a block that ended early or has fewer than 64 decisions, the partial last strip,
@@ -2705,6 +3214,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, pipe ? 65 : 0, 0);
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, pipe ? 65 : 0, 32);
     rows_per_wg = pipe ? rows64 : rows;
+    used = pipe ? kSweepPipe64 : kSweepMulti;
 #ifndef LPX_STEADY_PARTIAL
 #define LPX_STEADY_PARTIAL 1
 #endif
@@ -2719,6 +3229,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     while (rows_per_tile > 8 && (int64_t)rows_per_tile * B.ld * 8 >= (int64_t)1 << 32) rows_per_tile -= 8;
     launch_sweep_tiles<32>(B, R, m_local, K, rows_per_tile, nt, A_src, s);
     rows_per_wg = rows_per_tile;
+    used = kSweepTiles;
   } else {
     // long runs of rows per workgroup (k_update_multi): the 2K doubles of pivot-row slices are fetched once per run
     const bool rows_given = rows_per_wg > 0;
@@ -2737,13 +3248,27 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
         rows48 = choose_pipe_rows(m_local, (int)(B.ld / 512), 2 * cus, 48);
         while (rows48 > 4 && (int64_t)rows48 * B.ld * 8 >= (int64_t)1 << 32) rows48 -= 4;   // 32-bit offsets
       }
-      launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
+      if (form == 1 || !R.zeros || !R.tickets || !R.col_packed) {   // round 2: batches parked in registers, runs of rows
+        launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
+        used = kSweepSteady;
+      } else if (form == 2) {   // LDS-DMA staging, runs of rows (diagnostics: the step between the two)
+        launch_sweep_dma(B, R, m_local, K, rows48, nt, A_src, s, 2 * cus);
+        used = kSweepDma;
+      } else {                  // default: LDS-DMA staging, every wave pulls its batches in address order
+        launch_sweep_pull(B, R, m_local, K, nt, A_src, s, 2 * cus);
+        used = kSweepPull;
+        rows48 = 4;             // (what lpx_state_get_info reports as the run length: one batch)
+      }
       if (B.ld % 512 != 0) launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);   // the partial last strip
       rows_per_wg = rows48;   // (what lpx_state_get_info reports: the kernel that did the work)
     } else
 #endif
+    {
       launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s);
+      used = kSweepMulti;
+    }
   }
+  if (kernel_used) *kernel_used = used;
   if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,

@@ -169,7 +169,9 @@ class LPState:
         rc = self._L.lpx_state_get_info(self._h, C.byref(out))
         if rc:
             raise_for_status(rc)
-        return {k: getattr(out, k) for k, _ in _lib.StateInfo._fields_ if k != "reserved"}
+        d = {k: getattr(out, k) for k, _ in _lib.StateInfo._fields_}
+        d["sweep_kernel_name"] = self._L.lpx_sweep_kernel_name(d["sweep_kernel"]).decode()
+        return d
 
     def chain_trace(self):
         """Phase timestamps (100 MHz ticks) of the last decision launch: array [decisions, 5]; needs option

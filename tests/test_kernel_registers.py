@@ -137,3 +137,58 @@ def test_no_register_copy_reads_a_hand_issued_load_before_its_wait(device_asm, k
                     read = set().union(*[_regs(o) for o in ops])
                 assert not (read & landing), (name, ln, sorted(read & landing))
         assert loads >= 8, (name, loads)
+
+
+# ---- round 3: the LDS-DMA sweep kernels -------------------------------------------------------------------------------
+@pytest.mark.parametrize("kernel", ["k_sweep32_dma", "k_sweep32_pull"])
+def test_lds_dma_sweep_kernels_have_no_scratch(device_asm, kernel):
+    """Their tableau loads land in LDS, not in registers, but the pivot-row slices (128 VGPRs) must stay in registers
+    and two workgroups must fit a CU: no scratch, no AGPRs, at most 256 VGPRs, LDS <= 80 KiB."""
+    res = _resources(device_asm, kernel)
+    assert len(res) == 4, sorted(res)
+    for name, r in res.items():
+        assert r["private_seg_size"] == 0 and r["num_agpr"] == 0 and r["num_vgpr"] <= 256, (name, r)
+    lds = re.findall(r"\.amdhsa_group_segment_fixed_size (\d+)", "".join(
+        device_asm[m.start():m.start() + 4000] for m in re.finditer(r"\.amdhsa_kernel \S*%s" % kernel, device_asm)))
+    assert len(lds) == 4 and all(int(x) <= 80 * 1024 for x in lds), lds
+
+
+def test_pulled_tickets_are_not_touched_before_they_are_taken(device_asm):
+    """k_sweep32_pull's only hand-issued operation with a register destination is the ticket atomic.  Between the asm
+    statement that issues it and the v_readfirstlane that takes the ticket (behind a hand-written s_waitcnt vmcnt and
+    a scheduling barrier) no compiler-generated instruction may name that register — a copy made earlier would carry
+    the value from before the atomic returned (the hazard class of DESIGN.md 3a)."""
+    bodies = _kernel_bodies(device_asm, "k_sweep32_pull")
+    assert len(bodies) == 4, sorted(bodies)
+    for name, lines in bodies.items():
+        labels = {ln[:-1]: k for k, ln in enumerate(lines) if ln.endswith(":") and ln.startswith(".LBB")}
+        back = [labels[t] for k, ln in enumerate(lines) for t in re.findall(r"s_c?branch\S*\s+(\.LBB\S+)", ln)
+                if t in labels and labels[t] < k]
+        loop_start = min(back) if back else 0
+        in_asm = [False] * len(lines)
+        flag = False
+        for k, ln in enumerate(lines):
+            if ln.startswith(";;#ASMSTART"):
+                flag = True
+            in_asm[k] = flag
+            if ln.startswith(";;#ASMEND"):
+                flag = False
+        atomics = [(k, ln.split()[1].rstrip(",")) for k, ln in enumerate(lines)
+                   if in_asm[k] and ln.startswith("global_atomic_add")]
+        assert len(atomics) >= 9, (name, atomics)   # prologue 2 x 3, loop 3
+        for k, reg in atomics:
+            order = list(range(k + 1, len(lines))) + list(range(loop_start, k))
+            waited = False
+            taken = False
+            for j in order:
+                ln = lines[j]
+                if in_asm[j]:
+                    waited = waited or ln.startswith("s_waitcnt vmcnt")
+                    continue
+                if not ln or ln.startswith(";") or ln.endswith(":"):
+                    continue
+                if re.search(r"\b%s\b" % reg, ln):
+                    assert ln.startswith("v_readfirstlane_b32") and waited, (name, reg, ln, waited)
+                    taken = True
+                    break
+            assert taken, (name, reg)
