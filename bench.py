@@ -49,7 +49,7 @@ FP64_VALU_PEAK_TFLOPS = 39.3
 CHUNK = 1024
 
 
-def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traffic=None):
+def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traffic=None, traffic_source=None):
     """The bounded roofline figure of one row-update / sweep launch.
     One launch reads and writes every fp64 entry once (16*m*n bytes — counter-verified, profiles/) and performs
     2*m*n unfusable fp64 operations per pivot it applies.  Its time is bounded below by
@@ -59,7 +59,7 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
     (16*m*n bytes per pivot / 8 TB/s), which exceeds 1 when one sweep applies several pivots."""
     if not launches or not (avg_ms > 0):
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
-                "kernel": kernel, "launches_sampled": launches}
+                "traffic_source": traffic_source, "kernel": kernel, "launches_sampled": launches}
     t = avg_ms * 1e-3
     bytes_moved = 16.0 * m_local * n
     flops = 2.0 * m_local * n * pivots_per_launch
@@ -71,7 +71,7 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
            "peak": HBM_PEAK_GBS if hbm_bound else FP64_VALU_PEAK_TFLOPS,
            "unit": "GB/s" if hbm_bound else "TFLOP/s",
            "frac": max(t_hbm, t_valu) / t,
-           "traffic": traffic,
+           "traffic": traffic, "traffic_source": traffic_source,
            "kernel": kernel, "avg_kernel_ms": avg_ms, "launches_sampled": launches,
            "pivots_per_launch": pivots_per_launch,
            "lower_bound_ms": {"hbm": 1e3 * t_hbm, "fp64_valu": 1e3 * t_valu},
@@ -83,17 +83,72 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
     return out
 
 
-def load_traffic(workload, world, block):
-    """PMC-measured HBM bytes per launch (profiles/traffic_*.json, scripts/pmc_traffic.py) — only when that file was
-    measured for this workload, GPU count and pivots per sweep; otherwise None."""
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s_n%d.json" % (workload, world))
+def load_traffic(workload, world, block, kernel):
+    """PMC-measured HBM bytes per launch (profiles/traffic_*.json, scripts/pmc_traffic.py) and where the figure comes
+    from — only when that file was measured for this workload, GPU count, pivots per sweep AND kernel; otherwise
+    (None, None): the number is a property of another run (TCC counters cannot be read from inside bench.py)."""
+    name = "traffic_%s_n%d.json" % (workload, world)
     try:
-        t = json.load(open(tpath))
-        if int(t.get("pivots_per_sweep", -1)) == int(block):
-            return t.get("hbm_bytes_per_launch")
+        t = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if int(t.get("pivots_per_sweep", -1)) == int(block) and t.get("kernel") == kernel:
+            return t.get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "kernel": t.get("kernel"),
+                                                   "steps": t.get("steps"), "date": t.get("date"),
+                                                   "note": "rocprofv3 --pmc passes of this command on another box"}
     except Exception:
         pass
-    return None
+    return None, None
+
+
+def kernel_label(block, info, ld_is_whole_strips=True):
+    """The kernel the event-bracketed interval covers, as rocprofv3 names it (lpx_state_get_info)."""
+    if block == 1:
+        return "k_update"
+    name = (info or {}).get("sweep_kernel_name") or "k_update_multi"
+    return name
+
+
+class PowerSampler:
+    """Board power (hwmon power1_average, microwatts) and shader clock (pp_dpm_sclk) of the GPU sampled from a host
+    thread while a loop runs: the blocked sweep sits at the package power cap (profiles/r03_power_cap.txt)."""
+
+    def __init__(self, index=0, period_s=0.004):
+        import glob
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
+        self.caps = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap"))
+        self.index, self.period, self.samples, self._stop, self._t = index, period_s, [], False, None
+
+    def _read(self, path):
+        try:
+            return int(open(path).read().strip()) * 1e-6
+        except Exception:
+            return None
+
+    def __enter__(self):
+        import threading
+        if self.paths:
+            path = self.paths[min(self.index, len(self.paths) - 1)]
+
+            def run():
+                while not self._stop:
+                    v = self._read(path)
+                    if v is not None:
+                        self.samples.append(v)
+                    time.sleep(self.period)
+            self._t = threading.Thread(target=run, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._t is not None:
+            self._t.join()
+
+    def summary(self):
+        if not self.samples:
+            return None
+        cap = self._read(self.caps[min(self.index, len(self.caps) - 1)]) if self.caps else None
+        return {"samples": len(self.samples), "mean_W": float(np.mean(self.samples)), "max_W": float(np.max(self.samples)),
+                "cap_W": cap, "source": "hwmon power1_average sampled every %.0f ms from the host" % (1e3 * self.period)}
 
 
 def parity_after(st, A, b, c, pivots, m, n, threads, max_pivots):
@@ -239,9 +294,14 @@ def main():
     ap.add_argument("--no-cfg3", action="store_true",
                     help="N=1, cfg4: skip the extra `cfg3` object (BASELINE.md quotes its single-GPU roofline target on "
                          "cfg3, so it is measured in the same run by default; a profile of ONE workload wants it off)")
+    ap.add_argument("--no-steady", action="store_true",
+                    help="N=1, cfg4: skip the `steady` object (the default loop for --steady-steps pivots after "
+                         "--steady-warmup, cfg4 and cfg3, added when the headline run itself is shorter than that)")
+    ap.add_argument("--steady-steps", type=int, default=512)
+    ap.add_argument("--steady-warmup", type=int, default=64)
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the oracle replay that checks what the timed region computed")
-    ap.add_argument("--parity-max-pivots", type=int, default=1200,
+    ap.add_argument("--parity-max-pivots", type=int, default=1300,
                     help="largest warm-up + steps the oracle replay is run for (cfg4: ~30 ms per pivot on 16 threads)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="lpx_state_set_option on the timed handle (names: linear_programming_solver_amd._lib.OPTIONS)")
@@ -335,36 +395,61 @@ def main():
         k, v = kv.split("=", 1)
         options[k] = int(v)
 
-    def run_single(Aw, bw, cw, mw, nw):
-        """warm-up + timed region of the single-GPU device loop on one workload; returns the measurements"""
+    def run_single(Aw, bw, cw, mw, nw, steps=None, warmup=None, st=None, done=0, power=False):
+        """warm-up + timed region of the single-GPU device loop on one workload; returns the measurements.
+        st: continue on this handle (it has done `done` pivots) instead of uploading the tableau again."""
+        Ks = K if steps is None else steps
+        Ws = W if warmup is None else warmup
         t_up = time.perf_counter()
-        st = LPState(Aw, bw, cw, device=local_rank, options=options)
+        if st is None:
+            st = LPState(Aw, bw, cw, device=local_rank, options=options)
         t_up = time.perf_counter() - t_up
-        status, piv, _ = st.simplex_loop(max_pivots=W)
-        assert piv == W, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
+        status, piv, _ = st.simplex_loop(max_pivots=Ws)
+        assert piv == Ws, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
         block = st.block()
         # one-pass form: sample every N-th row update (an event pair costs ~3 us); blocked form: few, long sweeps: all
         st.profile_enable(args.event_every if block == 1 else (1 if args.event_every > 0 else 0))
+        sampler = PowerSampler(local_rank) if power else None
         barrier()
+        if sampler:
+            sampler.__enter__()
         t0 = time.perf_counter()
-        status, piv, _ = st.simplex_loop(max_pivots=K)
+        status, piv, _ = st.simplex_loop(max_pivots=Ks)
         barrier()
         elapsed = time.perf_counter() - t0
+        if sampler:
+            sampler.__exit__()
         launches, kernel_ms = st.profile_read()
         st.profile_enable(False)
-        assert piv == K, "timed region did %d pivots instead of %d (status %d)" % (piv, K, status)
+        assert piv == Ks, "timed region did %d pivots instead of %d (status %d)" % (piv, Ks, status)
         if block > 1:
             # blocked pivoting: blocks of `block` decisions while the budget lasts, the tail (incl. the decision that
             # only reports the end of the budget) in one last block; a block made of that decision alone has no sweep
-            expect = 0 if args.event_every <= 0 else (K + block) // block if (K % block) else K // block
-            pivots_per_launch = K / float(launches) if launches else float("nan")
+            expect = 0 if args.event_every <= 0 else (Ks + block) // block if (Ks % block) else Ks // block
+            pivots_per_launch = Ks / float(launches) if launches else float("nan")
         else:
-            expect = 0 if args.event_every <= 0 else (K + args.event_every - 1) // args.event_every
+            expect = 0 if args.event_every <= 0 else (Ks + args.event_every - 1) // args.event_every
             pivots_per_launch = 1.0
         assert launches == expect, "sampled %d row-update launches, expected %d" % (launches, expect)
         avg_ms = kernel_ms / launches if launches else float("nan")
-        return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
-                "pivots_per_launch": pivots_per_launch, "upload_s": t_up, "info": st.info()}
+        return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms, "steps": Ks,
+                "warmup": Ws, "done": done + Ws + Ks, "pivots_per_launch": pivots_per_launch, "upload_s": t_up,
+                "info": st.info(), "power": sampler.summary() if sampler else None}
+
+    def measured(r, mw, nw, name, Aw, bw, cw, with_parity):
+        """one measurement as an object of the JSON line: value, roofline of its sweep / row-update launch, oracle replay"""
+        kern = kernel_label(r["block"], r["info"])
+        traffic, tsrc = load_traffic(name, 1, r["block"], kern)
+        o = {"workload": "%s: m=%d n=%d, %d pivots after %d warm-up" % (name, mw, nw, r["steps"], r["warmup"]),
+             "value": r["steps"] / r["elapsed"], "unit": "pivots/s", "ms_per_step": 1e3 * r["elapsed"] / r["steps"],
+             "steps": r["steps"], "warmup": r["warmup"], "pivots_per_sweep": r["block"],
+             "roofline": roofline_block(mw, nw, r["pivots_per_launch"], r["avg_ms"], kern, r["launches"], traffic, tsrc)}
+        if r.get("power"):
+            o["board_power"] = r["power"]
+        if with_parity:
+            o["parity_after_timed_region"] = parity_after(r["st"], Aw, bw, cw, r["done"], mw, nw, host_cores(),
+                                                          args.parity_max_pivots)
+        return o
 
     def peer_selfcheck(devices):
         """Before anything is timed on a device set that has never been exercised together: a small LP through the
@@ -530,9 +615,8 @@ def main():
                            "single GPU" if not sharded else "row-block x%d, 1 all_gather/pivot, %s" % (
                                world, ("blocked x%d" % block) if block > 1 else
                                ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline)))},
-            "roofline": roofline_block(m_local, n, pivots_per_launch, avg_ms,
-                                       "k_update" if block == 1 else "k_update_multi", launches,
-                                       load_traffic(args.workload, world, block)),
+            "roofline": roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel_label(block, info), launches,
+                                       *load_traffic(args.workload, world, block, kernel_label(block, info))),
             "objective_after_timed_region": objective,
             "host_gen_s": t_gen,
             "host_upload_s": t_up,   # hipMalloc + PCIe upload of this rank's tableau; outside the timed region
@@ -545,24 +629,45 @@ def main():
         if (peer or (world == 1 and not sharded)) and not args.no_parity:
             # the checker: the same LP replayed on the fp64 oracle for warm-up + steps pivots (outside the timed region)
             line["parity_after_timed_region"] = parity_after(st, A, b, c, W + K, m, n, host_cores(), args.parity_max_pivots)
-        if world == 1 and not sharded and not peer and args.workload == "cfg4" and not args.no_cfg3:
+        line["devices_visible"] = torch.cuda.device_count()
+        single = world == 1 and not sharded and not peer
+        steady = {}
+        want_steady = single and args.workload == "cfg4" and not args.no_steady
+
+        def steady_leg(r_first, Aw, bw, cw, mw, nw, name):
+            """The steady state of the default loop (>= 512 pivots after >= 64 warm-up), driver-run: the headline of a
+            short command (the driver's 20 steps: one decision launch + one sweep, nothing overlapped, clocks still
+            ramping) says little about the loop a solve spends its time in.  Continues on the same handle."""
+            if r_first["steps"] >= args.steady_steps and r_first["warmup"] >= args.steady_warmup:
+                return None   # the headline IS a steady-state measurement
+            rs = run_single(None, None, None, mw, nw, steps=args.steady_steps, warmup=args.steady_warmup,
+                            st=r_first["st"], done=r_first["done"], power=True)
+            return measured(rs, mw, nw, name, Aw, bw, cw, not args.no_parity)
+
+        if want_steady:
+            r1_["done"] = W + K
+            leg = steady_leg(r1_, A, b, c, m, n, "cfg4")
+            if leg is not None:
+                steady["cfg4"] = leg
+        if single and args.workload == "cfg4" and not args.no_cfg3:
             # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
             # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)
             st.close()
             m3, n3 = WORKLOADS["cfg3"]
             A3, b3, c3 = gen_rows(m3, n3, args.seed, 0, m3)
             r3 = run_single(A3, b3, c3, m3, n3)
-            line["cfg3"] = {"workload": "cfg3: m=8192 n=16384, %d pivots after %d warm-up" % (K, W),
-                            "value": K / r3["elapsed"], "unit": "pivots/s", "ms_per_step": 1e3 * r3["elapsed"] / K,
-                            "pivots_per_sweep": r3["block"],
-                            "roofline": roofline_block(m3, n3, r3["pivots_per_launch"], r3["avg_ms"],
-                                                       "k_update" if r3["block"] == 1 else "k_update_multi",
-                                                       r3["launches"], load_traffic("cfg3", 1, r3["block"]))}
-            if not args.no_parity:
-                line["cfg3"]["parity_after_timed_region"] = parity_after(r3["st"], A3, b3, c3, W + K, m3, n3,
-                                                                         host_cores(), args.parity_max_pivots)
+            line["cfg3"] = measured(r3, m3, n3, "cfg3", A3, b3, c3, not args.no_parity)
+            if want_steady:
+                leg = steady_leg(r3, A3, b3, c3, m3, n3, "cfg3")
+                if leg is not None:
+                    steady["cfg3"] = leg
             r3["st"].close()
             del A3, b3, c3
+        if steady:
+            steady["protocol"] = ("the default loop continued on the same handle: %d more warm-up pivots, then %d timed "
+                                  "pivots; roofline of its sweep launches; oracle replay of ALL pivots the handle has done"
+                                  % (args.steady_warmup, args.steady_steps))
+            line["steady"] = steady
         if world == 1 and not peer and not args.no_cpu_baseline:
             rows_s = min(m, 8192)
             line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))

@@ -292,7 +292,9 @@ typedef struct lpx_solve_options {
   lpx_state** keep_state;       /* optional: receive the final LPState handle instead of destroying it    */
   int32_t pricing;              /* 0 = the reference's entering rule (default); 1 = Dantzig, see            */
                                 /* lpx_state_set_pricing                                                   */
-  int32_t restore_order_len;    /* entries of restore_order; <= 0: n (every original variable has a name)  */
+  int32_t restore_order_len;    /* entries of restore_order; < 0: n (every original variable has a name).  With a
+                                 * non-NULL restore_order, 0 means NO variable is substituted (an empty keySet());
+                                 * a NULL restore_order selects the default-name order over all n variables          */
 } lpx_solve_options;
 
 /* BigDecimal LPSolver.solve(LPStandardForm stForm)                      LPSolver.java:78

@@ -134,25 +134,8 @@ int push_ctl(lpx_state* s) {
   return 0;
 }
 
-void free_state(lpx_state* s) {
-  if (!s) return;
-  (void)hipSetDevice(s->device);
-  if (s->stream) (void)hipStreamSynchronize(s->stream);
-  for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
-  (void)hipFree(s->A_base[0]);
-  (void)hipFree(s->A_base[1]);
-  (void)hipFree(s->b_base[0]);
-  (void)hipFree(s->b_base[1]);
-  (void)hipFree(s->B.c);
-  (void)hipFree(s->B.prow);
-  (void)hipFree(s->B.col[0]);
-  (void)hipFree(s->B.col[1]);
-  (void)hipFree(s->B.partial);
-  (void)hipFree(s->B.perm);
-  (void)hipFree(s->B.ctl);
-  (void)hipFree(s->d_sum);
-  (void)hipFree(s->ring);
-  (void)hipFree(s->prow2);
+// Everything ensure_block_ring allocates; leaves the handle as if no ring had ever been built.
+static void free_block_ring(lpx_state* s) {
   (void)hipFree(s->R.prow);
   (void)hipFree(s->R.col);
   (void)hipFree(s->R.col0);
@@ -173,6 +156,30 @@ void free_state(lpx_state* s) {
   (void)hipFree(s->R.mg_mail);
   (void)hipFree(s->R.mg_arrive);
   (void)hipFree(s->d_cand);
+  s->R = lpxk::BlockRing{};
+  s->d_cand = nullptr;
+}
+
+void free_state(lpx_state* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
+  (void)hipFree(s->A_base[0]);
+  (void)hipFree(s->A_base[1]);
+  (void)hipFree(s->b_base[0]);
+  (void)hipFree(s->b_base[1]);
+  (void)hipFree(s->B.c);
+  (void)hipFree(s->B.prow);
+  (void)hipFree(s->B.col[0]);
+  (void)hipFree(s->B.col[1]);
+  (void)hipFree(s->B.partial);
+  (void)hipFree(s->B.perm);
+  (void)hipFree(s->B.ctl);
+  (void)hipFree(s->d_sum);
+  (void)hipFree(s->ring);
+  (void)hipFree(s->prow2);
+  free_block_ring(s);
   if (s->ev_upd) (void)hipEventDestroy(s->ev_upd);
 
   if (s->ev_peek) (void)hipEventDestroy(s->ev_peek);
@@ -464,18 +471,30 @@ extern "C" int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving) {
 }
 
 // ------------------------------------------------------------------------------------------------ blocked loop
+// Buffers that peer GPUs store into while this device's persistent kernel polls them (the pivot-row ring, the mailbox,
+// the arrival words of an lpx_multi shard) must be fine-grained: on coarse-grained memory system-scope accesses give no
+// cross-agent coherence inside a kernel, and the outcome would be a spin-bound failure or — worse — a stale pivot row.
+// No downgrade: if the runtime has no fine-grained device memory the multi-GPU handle cannot be built, and says so.
 hipError_t peer_visible_malloc(const lpx_state* s, void** ptr, size_t bytes) {
-  if (s->peer_written) {
-    if (hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained) == hipSuccess) return hipSuccess;
-    (void)hipGetLastError();  // no fine-grained device memory on this runtime: ordinary memory, system-scope accesses
-  }
+  if (s->peer_written) return hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained);
   return hipMalloc(ptr, bytes);
 }
 
 int32_t state_n(const lpx_state* s) { return s->n; }
 
+static int build_block_ring(lpx_state* s);
 int ensure_block_ring(lpx_state* s) {
   if (s->R.prow) return 0;
+  const int rc = build_block_ring(s);
+  if (rc) {   // all or nothing: a half-built ring would make the next call return 0 with NULL pointers inside
+    const std::string why = g_last_error;
+    free_block_ring(s);
+    if (s->peer_written) return fail(rc, (why + " (ring of a multi-GPU shard: peer-written buffers need fine-grained device memory)").c_str());
+    g_last_error = why;
+  }
+  return rc;
+}
+static int build_block_ring(lpx_state* s) {
   const int64_t mp = std::max<int64_t>(2, round_up(s->m, 2)) + 2;
   s->R.mp = mp;
   const size_t K = 2 * lpxk::kBlockMax;  // two halves: the block being decided and the one being swept

@@ -23,6 +23,14 @@ int fail(int status, const std::string& msg);
       return fail(LPX_DEVICE_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e));       \
   } while (0)
 
+// The multi-GPU entry points set the current HIP device shard by shard; the caller (torch, a JVM thread) gets its own
+// device back when the call returns.
+struct DeviceRestore {
+  int d = -1;
+  DeviceRestore() { if (hipGetDevice(&d) != hipSuccess) { d = -1; (void)hipGetLastError(); } }
+  ~DeviceRestore() { if (d >= 0) (void)hipSetDevice(d); }
+};
+
 // ------------------------------------------------------------------------------------------------ state
 struct lpx_state {
   int device = 0;

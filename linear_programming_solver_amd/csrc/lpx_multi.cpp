@@ -29,6 +29,7 @@ struct lpx_multi {
   std::vector<hipEvent_t> ev[2];
   int seq = 0;                        // decision-kernel launches so far (the SAME number on every shard: tags)
   bool distinct_devices = false;
+  bool fences_chosen = false;         // lpx_multi_set_option(LPX_OPT_CHAIN_FENCES) was called: honour it
 };
 
 static int shard_of(const lpx_multi* M, int32_t row) {
@@ -127,14 +128,20 @@ int multi_create(int32_t m, int32_t n, int32_t n_cap, const double* A, int64_t l
 
 extern "C" int lpx_multi_create(int32_t m, int32_t n, const double* A, int64_t lda, const double* b, const double* c,
                                 double v, const int32_t* perm, const int32_t* devices, int32_t n_dev, lpx_multi** out) {
+  DeviceRestore keep_device;
   if (n > 0 && !c) return fail(LPX_BAD_ARGUMENT, "lpx_multi_create: NULL array");
   return multi_create(m, n, n, A, lda, b, c, v, perm, devices, n_dev, out);
 }
 
-extern "C" void lpx_multi_destroy(lpx_multi* M) { multi_free(M); }
+extern "C" void lpx_multi_destroy(lpx_multi* M) {
+  DeviceRestore keep_device;
+  multi_free(M);
+}
 
 extern "C" int lpx_multi_set_option(lpx_multi* M, int32_t key, int64_t value) {
   if (!M) return fail(LPX_BAD_ARGUMENT, "lpx_multi_set_option: NULL handle");
+  DeviceRestore keep_device;
+  if (key == LPX_OPT_CHAIN_FENCES) M->fences_chosen = true;
   for (lpx_state* s : M->sh)
     if (int rc = lpx_state_set_option(s, key, value)) return rc;
   return 0;
@@ -148,11 +155,13 @@ extern "C" int lpx_multi_set_pricing(lpx_multi* M, int32_t pricing) {
 }
 
 extern "C" int lpx_multi_get_entering(lpx_multi* M, int32_t* entering) {
+  DeviceRestore keep_device;
   if (!M || !entering) return fail(LPX_BAD_ARGUMENT, "lpx_multi_get_entering: NULL argument");
   return lpx_get_entering(M->sh[0], entering);   // c is replicated
 }
 
 extern "C" int lpx_multi_get_leaving(lpx_multi* M, int32_t entering, int32_t* leaving, double* ratio) {
+  DeviceRestore keep_device;
   if (!M || !leaving) return fail(LPX_BAD_ARGUMENT, "lpx_multi_get_leaving: NULL argument");
   // the strict '<' scan from row 0 upwards (LPState.java:292-303) = lexicographic minimum of (ratio, global row)
   double best = lpxk::kInf;
@@ -184,6 +193,7 @@ static lpxk::MgPeers peers_of(const lpx_multi* M, int r) {
 // host: this is the forced first pivot / the degenerate pivot of phase 1, LPSolver.java:138, :195, not the loop),
 // then every shard finishes the pivot identically (k_commit) and updates its own rows.
 extern "C" int lpx_multi_pivot(lpx_multi* M, int32_t entering, int32_t leaving) {
+  DeviceRestore keep_device;
   if (!M) return fail(LPX_BAD_ARGUMENT, "lpx_multi_pivot: NULL handle");
   const int32_t n = state_n(M->sh[0]);
   if (!(entering >= 0 && entering < n) || !(leaving >= 0 && leaving < M->m))
@@ -351,6 +361,7 @@ static int multi_loop_overlapped(lpx_multi* M, int K, int64_t max_pivots, int wa
 // per device, exchanging among themselves), then one sweep per device.
 extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t* pivots_done, int32_t* status,
                                       int32_t* track_slot) {
+  DeviceRestore keep_device;
   if (!M) return fail(LPX_BAD_ARGUMENT, "lpx_multi_simplex_loop: NULL handle");
   const int G = M->n_dev;
   // pivots per sweep: by the largest shard (every device must take the same decisions in the same blocks)
@@ -361,13 +372,24 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
     work = std::max<int64_t>(work, std::max<int64_t>(M->sh[r]->m, M->sh[r]->B.ld));
   }
   K = std::min(K, (int)lpxk::kShardBlockMax);
+  bool ring_built = false;
   for (int r = 0; r < G; r++) {
     lpx_state* s = M->sh[r];
     HIP_TRY(hipSetDevice(M->device[r]));
     if (int rc = set_running(s, max_pivots, track_slot ? *track_slot : -1)) return rc;
+    ring_built = ring_built || s->R.prow == nullptr;
     if (int rc = ensure_block_ring(s)) return rc;
     launch_seed_entering(s);
     HIP_TRY(hipGetLastError());
+  }
+  if (ring_built) {
+    // A new ring's mailbox, arrival words and pivot-row ring are zeroed by memsets queued on the shard's OWN stream,
+    // and a peer's decision kernel stores into them as soon as IT runs: every memset must have landed before any
+    // decision kernel of the set is launched (a late memset would erase a candidate and its reader would spin out).
+    for (int r = 0; r < G; r++) {
+      HIP_TRY(hipSetDevice(M->device[r]));
+      HIP_TRY(hipStreamSynchronize(M->sh[r]->stream));
+    }
   }
   // grid of the decision kernels: the same on every device, never more than any device holds resident — shards
   // that share a GPU share its CUs (their kernels spin on each other)
@@ -384,8 +406,8 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
   }
   for (int r = 0; r < G; r++) { M->sh[r]->info.chain_wgs = wgs; M->sh[r]->info.overlapped = 0; M->sh[r]->info.chain_stream_masked = 0; }
   // across real devices the conservative barrier form (release + acquire around every exchange) unless the caller
-  // chose one: the fence-free form is validated inside one device only
-  const int fences = M->distinct_devices ? 3 : (int)M->sh[0]->opt[LPX_OPT_CHAIN_FENCES];
+  // chose one with lpx_multi_set_option: the fence-free form is validated inside one device only
+  const int fences = (M->distinct_devices && !M->fences_chosen) ? 3 : (int)M->sh[0]->opt[LPX_OPT_CHAIN_FENCES];
   const bool trace = M->sh[0]->opt[LPX_OPT_CHAIN_TRACE] != 0;
   const int dantzig = M->sh[0]->pricing == 1;
 
@@ -469,6 +491,7 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
 }
 
 extern "C" int lpx_multi_read(lpx_multi* M, double* A, int64_t lda, double* b, double* c, double* v, int32_t* perm) {
+  DeviceRestore keep_device;
   if (!M) return fail(LPX_BAD_ARGUMENT, "lpx_multi_read: NULL handle");
   for (int r = 0; r < M->n_dev; r++) {
     const int32_t r0 = M->row_start[r];
@@ -480,6 +503,7 @@ extern "C" int lpx_multi_read(lpx_multi* M, double* A, int64_t lda, double* b, d
 }
 
 extern "C" int lpx_multi_checksum(lpx_multi* M, uint64_t out[3]) {
+  DeviceRestore keep_device;
   if (!M || !out) return fail(LPX_BAD_ARGUMENT, "lpx_multi_checksum: NULL argument");
   out[0] = out[1] = out[2] = 0;
   for (int r = 0; r < M->n_dev; r++) {
@@ -500,11 +524,13 @@ extern "C" int lpx_multi_profile_enable(lpx_multi* M, int enable) {
 }
 
 extern "C" int lpx_multi_profile_read(lpx_multi* M, int32_t shard, int64_t* launches, double* total_ms) {
+  DeviceRestore keep_device;
   if (!M || shard < 0 || shard >= M->n_dev) return fail(LPX_BAD_ARGUMENT, "lpx_multi_profile_read: bad argument");
   return lpx_profile_read(M->sh[shard], launches, total_ms);
 }
 
 extern "C" int lpx_multi_get_info(lpx_multi* M, lpx_state_info* out) {
+  DeviceRestore keep_device;
   if (!M || !out) return fail(LPX_BAD_ARGUMENT, "lpx_multi_get_info: NULL argument");
   return lpx_state_get_info(M->sh[0], out);
 }

@@ -296,7 +296,7 @@ extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, con
     if (status == LPX_OPTIMAL) {
       // restoreInitialLP :200-246
       status = lpx_restore_initial_lp(s, c0.data(), n, x0, o.restore_order,
-                                      o.restore_order ? (o.restore_order_len > 0 ? o.restore_order_len : n) : 0);
+                                      o.restore_order ? (o.restore_order_len < 0 ? n : o.restore_order_len) : 0);
       if (status == LPX_DEVICE_ERROR) { res->status = status; return status; }
     }
   }
@@ -433,9 +433,13 @@ int multi_restore_initial_lp(lpx_multi* M, const double* c0, int32_t n, int32_t 
   const size_t nb_rows = std::max<size_t>(1, basic_rows.size());
   double *gA = nullptr, *gb = nullptr;
   lpxk::RestoreEntry* d_ent = nullptr;
+  struct Temps {   // freed on every way out (on shard 0's device: hipFree does not depend on the current device)
+    double *&a, *&b; lpxk::RestoreEntry*& e;
+    ~Temps() { (void)hipFree(a); (void)hipFree(b); (void)hipFree(e); a = b = nullptr; e = nullptr; }
+  } temps{gA, gb, d_ent};
   HIP_TRY(hipSetDevice(multi_device(M, 0)));
   HIP_TRY(hipMalloc((void**)&gA, nb_rows * (size_t)ld * sizeof(double)));
-  if (hipMalloc((void**)&gb, nb_rows * sizeof(double)) != hipSuccess) { (void)hipFree(gA); return fail(LPX_DEVICE_ERROR, "hipMalloc failed"); }
+  HIP_TRY(hipMalloc((void**)&gb, nb_rows * sizeof(double)));
   int rc = 0;
   for (size_t t = 0; t < basic_rows.size() && rc == 0; t++) {
     const int o = multi_owner(M, basic_rows[t]);
@@ -475,7 +479,6 @@ int multi_restore_initial_lp(lpx_multi* M, const double* c0, int32_t n, int32_t 
       else vnew = s0->h_ctl->v;
     }
   }
-  (void)hipFree(gA); (void)hipFree(gb); (void)hipFree(d_ent);
   if (rc) return rc;
   std::vector<int32_t> np;                                                           // :235-244
   np.reserve((size_t)n + m);
@@ -494,6 +497,7 @@ extern "C" int lpx_solve_multi(int32_t m, int32_t n, const double* A, int64_t ld
                                int32_t maximize, const lpx_solve_options* opts, const int32_t* devices, int32_t n_dev,
                                lpx_solve_result* res) {
   if (!res) return fail(LPX_BAD_ARGUMENT, "lpx_solve_multi: result is NULL");
+  DeviceRestore keep_device;
   memset(res, 0, sizeof *res);
   res->x0_slot = -1;
   res->status = LPX_BAD_ARGUMENT;
@@ -592,7 +596,7 @@ extern "C" int lpx_solve_multi(int32_t m, int32_t n, const double* A, int64_t ld
     }
     if (status == LPX_OPTIMAL) {                                                     // restoreInitialLP :200-246
       status = multi_restore_initial_lp(M, c0.data(), n, x0, o.restore_order,
-                                        o.restore_order ? (o.restore_order_len > 0 ? o.restore_order_len : n) : 0);
+                                        o.restore_order ? (o.restore_order_len < 0 ? n : o.restore_order_len) : 0);
       if (status == LPX_DEVICE_ERROR || status == LPX_BAD_ARGUMENT) { res->status = status; return status; }
     }
   }

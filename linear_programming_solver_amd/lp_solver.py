@@ -59,8 +59,9 @@ class LPSolver:
             order = np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))
         elif st_form.has_variable_names() and n > 0:
             order = self._key_set_order(st_form)
-        if order is not None and order.size:
-            opts.restore_order = order.ctypes.data_as(_lib.ip)
+        if order is not None:   # an empty key set substitutes nothing (LPSolver.java:217 iterates zero names)
+            keep = order if order.size else np.zeros(1, dtype=np.int32)
+            opts.restore_order = keep.ctypes.data_as(_lib.ip)
             opts.restore_order_len = int(order.size)
         perm = np.zeros(n + m, dtype=np.int32)
         x = np.zeros(max(n, 1), dtype=np.float64)

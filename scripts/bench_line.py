@@ -15,3 +15,10 @@ if "cfg3" in j:
     print(tag, "cfg3", round(j["cfg3"]["value"], 1), "pivots/s sweep", round((r3.get("avg_kernel_ms") or 0) * 1e3, 1),
           "us frac", None if r3["frac"] is None else round(r3["frac"], 3), "parity",
           (j["cfg3"].get("parity_after_timed_region") or {}).get("ok"))
+for name, leg in (j.get("steady") or {}).items():
+    if not isinstance(leg, dict):
+        continue
+    rs = leg["roofline"]
+    print(tag, "steady", name, round(leg["value"], 1), "pivots/s;", rs.get("kernel"), round((rs.get("avg_kernel_ms") or 0) * 1e3, 1),
+          "us x", rs["launches_sampled"], "frac", None if rs["frac"] is None else round(rs["frac"], 3), "parity",
+          (leg.get("parity_after_timed_region") or {}).get("ok"), "power", leg.get("board_power"))

@@ -1,7 +1,7 @@
 """HBM bytes per launch of one kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), corrected as
 MI355X_MICROARCH.md's HBM section prescribes for gfx950 (FETCH_SIZE counts 128-B requests as 64 B: x2; both
 counters are in KiB).  Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv>
-<kernel substring> <m> <n> <label> <pivots_per_sweep>  -> JSON on stdout (profiles/traffic_<workload>_n1.json;
+<kernel substring> <m> <n> <label> <pivots_per_sweep> [<steps of the profiled command>]  -> JSON on stdout (profiles/traffic_<workload>_n1.json;
 bench.py quotes it as roofline.traffic only when workload, GPU count and pivots per sweep match its own run).
 
 Only FULL launches are averaged: those whose counter value is within 5 % of the largest one (the warm-up and the
@@ -27,6 +27,7 @@ def main():
     fpath, wpath, ksub, m, n, label = sys.argv[1:7]
     m, n = int(m), int(n)
     block = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+    steps = int(sys.argv[8]) if len(sys.argv) > 8 else None
     f = per_launch(fpath, "FETCH_SIZE", ksub)
     w = per_launch(wpath, "WRITE_SIZE", ksub)
     one_pass = 16.0 * m * n
@@ -37,6 +38,8 @@ def main():
         "workload": label,
         "pivots_per_sweep": block,
         "kernel": ksub,
+        "steps": steps,
+        "date": __import__("datetime").date.today().isoformat(),
         "launches_sampled": [len(f), len(w)],
         "FETCH_SIZE_KiB_mean": fmean,
         "WRITE_SIZE_KiB_mean": wmean,
