@@ -113,7 +113,8 @@ class PowerSampler:
 
     def __init__(self, index=0, period_s=0.004):
         import glob
-        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) or sorted(
+            glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
         self.caps = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap"))
         self.index, self.period, self.samples, self._stop, self._t = index, period_s, [], False, None
 
@@ -148,7 +149,7 @@ class PowerSampler:
             return None
         cap = self._read(self.caps[min(self.index, len(self.caps) - 1)]) if self.caps else None
         return {"samples": len(self.samples), "mean_W": float(np.mean(self.samples)), "max_W": float(np.max(self.samples)),
-                "cap_W": cap, "source": "hwmon power1_average sampled every %.0f ms from the host" % (1e3 * self.period)}
+                "cap_W": cap, "source": "hwmon power1_average / power1_input sampled every %.0f ms from the host" % (1e3 * self.period)}
 
 
 def parity_after(st, A, b, c, pivots, m, n, threads, max_pivots):
@@ -297,6 +298,10 @@ def main():
     ap.add_argument("--no-steady", action="store_true",
                     help="N=1, cfg4: skip the `steady` object (the default loop for --steady-steps pivots after "
                          "--steady-warmup, cfg4 and cfg3, added when the headline run itself is shorter than that)")
+    ap.add_argument("--no-onepass", action="store_true",
+                    help="skip the `onepass` object: the bandwidth-bound schedule north_star describes (one tableau pass "
+                         "per pivot at N=1; two pivots per pass, the smallest block of the multi-GPU handle, at every N)")
+    ap.add_argument("--onepass-steps", type=int, default=96)
     ap.add_argument("--steady-steps", type=int, default=512)
     ap.add_argument("--steady-warmup", type=int, default=64)
     ap.add_argument("--no-parity", action="store_true",
@@ -503,6 +508,27 @@ def main():
                 err = "%s: %s" % (type(ex).__name__, ex)
         barrier()
         elapsed = time.perf_counter() - t0
+        onepass, extra_pivots = None, 0
+        if rank == 0 and err is None and not args.no_onepass:
+            # the bandwidth-bound leg: blocks of 2 pivots (the smallest the multi-GPU handle runs), so that a scaling
+            # record shows what row sharding multiplies (the sweep) next to the blocked number it barely changes
+            try:
+                info_main = mt.info()
+                mt.set_option("block", 2)
+                mt.simplex_loop(max_pivots=16)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                st2, piv2, _ = mt.simplex_loop(max_pivots=args.onepass_steps)
+                dt = time.perf_counter() - t1
+                extra_pivots = 16 + int(piv2)
+                onepass = {"pivots_per_pass": 2, "steps": int(piv2), "value": piv2 / dt, "unit": "pivots/s",
+                           "ms_per_step": 1e3 * dt / max(1, piv2),
+                           "what": "lpx_multi with blocks of 2 pivots: per pivot half a pass over every shard's rows "
+                                   "(16*m*n/2 bytes in all) + one decision"}
+                mt.set_option("block", info_main["block"] if info_main["block"] > 2 else 0)
+            except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
+                onepass = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        barrier()
         if dist is not None:
             box = [err]
             dist.broadcast_object_list(box, src=0)
@@ -523,7 +549,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return {"st": mt, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
-                "pivots_per_launch": ppl, "upload_s": t_up, "info": info}
+                "pivots_per_launch": ppl, "upload_s": t_up, "info": info, "onepass": onepass, "pivots_done": W + K + extra_pivots}
 
     fallback_reason = None
     if peer:
@@ -628,8 +654,12 @@ def main():
                                                                      "rccl, after the lpx_multi path failed: " + fallback_reason)
         if (peer or (world == 1 and not sharded)) and not args.no_parity:
             # the checker: the same LP replayed on the fp64 oracle for warm-up + steps pivots (outside the timed region)
-            line["parity_after_timed_region"] = parity_after(st, A, b, c, W + K, m, n, host_cores(), args.parity_max_pivots)
+            # (on the multi-GPU handle the bandwidth-bound leg has run behind the timed region: the replay covers it too)
+            line["parity_after_timed_region"] = parity_after(st, A, b, c, r1_.get("pivots_done", W + K) if peer else W + K,
+                                                             m, n, host_cores(), args.parity_max_pivots)
         line["devices_visible"] = torch.cuda.device_count()
+        if peer and r1_.get("onepass") is not None:
+            line["onepass"] = r1_["onepass"]
         single = world == 1 and not sharded and not peer
         steady = {}
         want_steady = single and args.workload == "cfg4" and not args.no_steady
@@ -649,6 +679,30 @@ def main():
             leg = steady_leg(r1_, A, b, c, m, n, "cfg4")
             if leg is not None:
                 steady["cfg4"] = leg
+        if single and not args.no_onepass:
+            # the schedule north_star describes, on the same handle: one pass per pivot (k_update: the 16*m*n-bytes-per-
+            # pivot roofline kernel), and two pivots per pass as the multi-GPU handle's bandwidth-bound leg runs them
+            def one_leg(block_opt, steps):
+                st.set_option("block", block_opt)
+                st.simplex_loop(max_pivots=8)
+                st.profile_enable(1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _, piv2, _ = st.simplex_loop(max_pivots=steps)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                ln, kms = st.profile_read()
+                st.profile_enable(False)
+                inf = st.info()
+                return {"pivots_per_pass": block_opt, "steps": int(piv2), "value": piv2 / dt, "unit": "pivots/s",
+                        "ms_per_step": 1e3 * dt / max(1, piv2),
+                        "roofline": roofline_block(m, n, piv2 / float(ln) if ln else float("nan"),
+                                                   kms / ln if ln else float("nan"), kernel_label(block_opt, inf), ln)}
+            try:
+                line["onepass"] = dict(one_leg(2, args.onepass_steps), one_pass_per_pivot=one_leg(1, args.onepass_steps // 2))
+                st.set_option("block", options.get("block", 0))
+            except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
+                line["onepass"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if single and args.workload == "cfg4" and not args.no_cfg3:
             # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
             # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)
