@@ -113,10 +113,26 @@ class PowerSampler:
 
     def __init__(self, index=0, period_s=0.004):
         import glob
-        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average")) or sorted(
-            glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
-        self.caps = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap"))
-        self.index, self.period, self.samples, self._stop, self._t = index, period_s, [], False, None
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+            pw = sorted(glob.glob(dev + "/hwmon/hwmon*/power1_average")) or sorted(glob.glob(dev + "/hwmon/hwmon*/power1_input"))
+            cap = sorted(glob.glob(dev + "/hwmon/hwmon*/power1_cap"))
+            if pw:
+                cards.append((os.path.basename(os.path.realpath(dev)), pw[0], cap[0] if cap else None))
+        # the card this process computes on, by PCI address (a box may expose the hwmon nodes of all GPUs of its host)
+        want = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        hit = [c for c in cards if c[0].lower() == (want or "").lower()]
+        self.card = hit[0] if hit else (cards[0] if len(cards) == 1 else None)
+        self.matched = want if hit else None
+        self.paths = [self.card[1]] if self.card else []
+        self.caps = [self.card[2]] if self.card and self.card[2] else []
+        self.index, self.period, self.samples, self._stop, self._t = 0, period_s, [], False, None
 
     def _read(self, path):
         try:
@@ -149,7 +165,8 @@ class PowerSampler:
             return None
         cap = self._read(self.caps[min(self.index, len(self.caps) - 1)]) if self.caps else None
         return {"samples": len(self.samples), "mean_W": float(np.mean(self.samples)), "max_W": float(np.max(self.samples)),
-                "cap_W": cap, "source": "hwmon power1_average / power1_input sampled every %.0f ms from the host" % (1e3 * self.period)}
+                "cap_W": cap, "pci": self.matched,
+                "source": "hwmon power1_average / power1_input sampled every %.0f ms from the host" % (1e3 * self.period)}
 
 
 def parity_after(st, A, b, c, pivots, m, n, threads, max_pivots):
