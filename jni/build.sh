@@ -14,4 +14,8 @@ LIBDIR="$HERE/../linear_programming_solver_amd"
 cc -O2 -fPIC -shared -I"$JAVA_HOME/include" -I"$JAVA_HOME/include/linux" "$HERE/lpx_jni.c" \
    -L"$LIBDIR" -llpx -Wl,-rpath,"$LIBDIR" -o "$LIBDIR/liblpxjni.so"
 "$JAVA_HOME/bin/javac" -d "$HERE/classes" "$HERE/java/lpsolver/LpxNative.java"
+# the drop-in LPSolverGpu needs the reference classes on the class path: LPX_REFERENCE_CLASSES=<dir or jar>
+if [ -n "$LPX_REFERENCE_CLASSES" ]; then
+  "$JAVA_HOME/bin/javac" -cp "$LPX_REFERENCE_CLASSES:$HERE/classes" -d "$HERE/classes" "$HERE/java/lpsolver/LPSolverGpu.java"
+fi
 echo "built $LIBDIR/liblpxjni.so and $HERE/classes/lpsolver/LpxNative.class"

@@ -33,3 +33,64 @@ def test_every_native_method_of_the_java_class_has_a_c_definition():
 def test_build_script_probes_for_a_jdk():
     sh = open(os.path.join(ROOT, "jni", "build.sh")).read()
     assert "JAVA_HOME" in sh and "jni.h" in sh
+
+
+JNI_TYPE = {"int": "jint", "long": "jlong", "double": "jdouble", "boolean": "jboolean", "double[]": "jdoubleArray",
+            "int[]": "jintArray", "long[]": "jlongArray", "String": "jstring", "void": "void"}
+
+
+def _java_natives():
+    """{method: (return type, [parameter types])} of jni/java/lpsolver/LpxNative.java"""
+    java = open(os.path.join(ROOT, "jni", "java", "lpsolver", "LpxNative.java")).read()
+    out = {}
+    for ret, name, params in re.findall(r"static\s+native\s+([\w\[\]]+)\s+(\w+)\s*\(([^)]*)\)", java):
+        types = [" ".join(p.split()[:-1]) for p in params.split(",") if p.strip()]
+        out[name] = (ret, types)
+    return out
+
+
+def _c_definitions():
+    """{method: (return type, [parameter types after JNIEnv*, jclass])} of jni/lpx_jni.c"""
+    c = open(SHIM).read()
+    out = {}
+    for ret, name, params in re.findall(r"JNIEXPORT\s+(\w+)\s+JNICALL\s+NAME\((\w+)\)\(([^)]*)\)", c):
+        types = [p.split()[0] for p in params.split(",")]
+        assert types[:2] == ["JNIEnv*", "jclass"], (name, types[:2])
+        out[name] = (ret, types[2:])
+    return out
+
+
+def test_each_native_signature_matches_its_c_definition():
+    """The JNI type string of every `native` declaration (LPSolver.java:78-114 / LPState.java:114, :274, :287 are what
+    they stand in for) against the parameter list of its C definition: a JVM would link a mismatching pair without
+    complaint and pass garbage."""
+    java, c = _java_natives(), _c_definitions()
+    assert set(java) == set(c)
+    for name, (ret, types) in java.items():
+        want = (JNI_TYPE[ret], [JNI_TYPE[t] for t in types])
+        assert c[name] == want, (name, c[name], want)
+
+
+def test_the_drop_in_solver_class_only_calls_declared_natives():
+    """jni/java/lpsolver/LPSolverGpu.java (the replacement of LPSolver.solve and of the LPState operator triple) uses
+    only methods LpxNative declares, with the declared number of arguments, and maps every lpx_status of lpx.h."""
+    src = open(os.path.join(ROOT, "jni", "java", "lpsolver", "LPSolverGpu.java")).read()
+    java = _java_natives()
+    calls = re.findall(r"LpxNative\.(\w+)\(", src)
+    assert calls and set(calls) <= set(java), set(calls) - set(java)
+    for m in re.finditer(r"LpxNative\.(\w+)\(", src):   # argument count by top-level commas
+        depth, k, args = 1, m.end(), 1
+        if src[k] == ")":
+            args = 0
+        while depth:
+            ch = src[k]
+            depth += ch in "([{"
+            depth -= ch in ")]}"
+            args += ch == "," and depth == 1
+            k += 1
+        assert args == len(java[m.group(1)][1]), (m.group(1), args)
+    lpx_h = open(os.path.join(ROOT, "include", "lpx.h")).read()
+    codes = {int(v) for v in re.findall(r"LPX_(?:OPTIMAL|UNBOUNDED|INFEASIBLE|AUX_UNBOUNDED|NO_DEGENERATE_PIVOT|"
+                                        r"BAD_ARGUMENT|RESTORE_INDEX_FAULT|DIVIDE_BY_ZERO)\s*=\s*(\d+)", lpx_h)}
+    handled = {int(v) for v in re.findall(r"case (\d+):", src)}
+    assert codes and codes <= handled, codes - handled
