@@ -530,8 +530,8 @@ static int build_block_ring(lpx_state* s) {
   // batches of 4 rows (1 KiB each)
   HIP_TRY(hipMalloc((void**)&s->R.tickets, (size_t)(s->B.ld / 128 + 4) * 128));
   HIP_TRY(hipMemsetAsync(s->R.tickets, 0, (size_t)(s->B.ld / 128 + 4) * 128, s->stream));
-  HIP_TRY(hipMalloc((void**)&s->R.col_packed, (size_t)(mp / 4 + 1) * 1024));
-  HIP_TRY(hipMemsetAsync(s->R.col_packed, 0, (size_t)(mp / 4 + 1) * 1024, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.col_packed, (size_t)(mp / 4 + 1) * 2048));
+  HIP_TRY(hipMemsetAsync(s->R.col_packed, 0, (size_t)(mp / 4 + 1) * 2048, s->stream));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));

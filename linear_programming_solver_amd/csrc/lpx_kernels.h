@@ -99,7 +99,7 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   double* chain_own_b;     // mp: b with all pending pivots applied
   long long* chain_dbg;    // diagnostics (LPX_OPT_CHAIN_TRACE): 5 timestamps per decision of the last block
   unsigned* census;        // [w] = XCC id + 1 of chain workgroup w; [kChainMaxWgs] = OR of (1 << XCC id) of sampled sweep workgroups
-  double* col_packed;      // k_sweep32_pull: the block's multipliers as [batch of 4 rows][pivot][row], (mp / 4) x 1 KiB
+  double* col_packed;      // k_sweep32_pull: the block's multipliers as [batch of 4 rows][pivot][row]: (mp / 4) x 1 KiB (2 KiB for blocks of 64)
   unsigned* tickets;       // k_sweep32_pull: one batch counter per 128-column sub-strip, 128 bytes apart (ld / 128 of them)
   const double* zeros;     // 256 bytes of +0.0: what k_sweep32_dma's multiplier DMA reads for the identity steps of a partly filled block
   // shards of an lpx_multi only (else NULL): written by the peers' decision kernels
@@ -145,7 +145,7 @@ int chain_blocks_per_cu();
 // form (blocks of 17..32 over the full strips): 0 = k_sweep32_pull (round 3: LDS-DMA staging, every wave pulls its
 // batches in address order), 1 = k_sweep32_steady (round 2: register staging, runs of rows), 2 = k_sweep32_dma (LDS-DMA
 // staging, runs of rows).  *kernel_used (may be NULL): the SweepKernel that took the bulk of the tableau.
-enum SweepKernel { kSweepNone = 0, kSweepTiles = 1, kSweepMulti = 2, kSweepSteady = 3, kSweepPipe64 = 4, kSweepDma = 5, kSweepPull = 6 };
+enum SweepKernel { kSweepNone = 0, kSweepTiles = 1, kSweepMulti = 2, kSweepSteady = 3, kSweepPipe64 = 4, kSweepDma = 5, kSweepPull = 6, kSweepPull64 = 7 };
 const char* sweep_kernel_name(int code);
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src = nullptr, const double* b_src = nullptr,

@@ -2318,13 +2318,14 @@ __device__ __forceinline__ int ticket_take(unsigned& tk) {   // behind a wait th
 // lines (measured: the sweep of a block whose multipliers all come from one line ran 9 % faster than a real one).  The
 // identity steps of a partly filled block (pivot >= np) get +0 here.  8 MiB at cfg4, a few microseconds in front of the
 // sweep on its stream.
+template <int KP>
 __global__ __launch_bounds__(256) void k_pack_multipliers(const double* __restrict__ col_ring, int64_t mp,
                                                           const LpxCtl* __restrict__ ring, int kmax, int nbt,
                                                           double* __restrict__ colT) {
   __shared__ int sh_np;
-  const int np = ring_count(ring, kDmaK, kmax, &sh_np);
-  const int s = threadIdx.x & 31;
-  const int64_t b = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int np = ring_count(ring, KP, kmax, &sh_np);
+  const int s = threadIdx.x % KP;
+  const int64_t b = (int64_t)blockIdx.x * (256 / KP) + threadIdx.x / KP;
   if (b >= nbt) return;
   d2 lo = d2{0.0, 0.0}, hi = d2{0.0, 0.0};
   if (s < np) {
@@ -2332,7 +2333,7 @@ __global__ __launch_bounds__(256) void k_pack_multipliers(const double* __restri
     lo = p[0];
     hi = p[1];
   }
-  d2* q = reinterpret_cast<d2*>(colT + b * 128 + s * 4);
+  d2* q = reinterpret_cast<d2*>(colT + b * (KP * 4) + s * 4);
   q[0] = lo;
   q[1] = hi;
 }
@@ -2467,6 +2468,208 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_pull(double* __restrict__ A,
     }
   }
   dma_wait<0>();   // the pending ticket atomics write registers of this wave: let them land before it ends
+}
+
+// ---- blocks of 33..64 pivots: k_sweep32_pull's worker split into a PAIR of waves (round 3) ---------------------------
+// 64 pivot-row slices do not fit one wave's registers, so a sub-strip's worker is two waves of one workgroup: stage 1
+// is k_sweep32_pull's loop over pivots 0..31 (tickets, LDS-DMA, hand-counted vmcnt) except that a finished batch goes
+// into a hand-over slot in LDS instead of to memory; stage 2 takes it from there (lane t reads what lane t wrote),
+// applies pivots 32..63 with multipliers it has brought itself (the ticket of batch i+2 is in an LDS ring long before:
+// stage 1 knows its tickets three batches ahead) and stores the rows.  The two waves meet only through LDS words —
+// `seq` (batches handed over), `used` (batches taken), `done` — polled with s_sleep; an LDS queue is in-order per wave,
+// so data written before a word is visible to whoever has seen the word.  Same arithmetic per entry as two passes of
+// 32; half the HBM bytes per pivot.  A block of fewer than 33 pivots is left to the generic two-pass path.
+constexpr int kPairHS = 3;                                              // hand-over slots
+constexpr int kPairBytes = kPullWaveBytes + kPairHS * kDmaSlotBytes + kPullNM * 1024 + 256;   // per pair: 32.25 KiB
+static_assert(4 * kPairBytes <= 160 * 1024, "two workgroups (four pairs) per CU");
+
+__device__ __forceinline__ void lds_word_store(int* p, int v) {
+  asm volatile("" ::: "memory");
+  *reinterpret_cast<volatile int*>(p) = v;
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ int lds_word_load(const int* p) {   // every lane reads the word; the result is made uniform
+  asm volatile("" ::: "memory");
+  const int v = *reinterpret_cast<const volatile int*>(p);
+  asm volatile("" ::: "memory");
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <bool NT, bool OOP>
+__global__ __launch_bounds__(256, 2) void k_sweep64_pull(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                         int64_t ld, int m_local,
+                                                         const double* __restrict__ prow_ring,
+                                                         const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
+                                                         const double* __restrict__ col_packed,   // [batch][64][4]
+                                                         unsigned* __restrict__ tickets) {
+  constexpr int K = 32, RB = kDmaRB, NS = kPullNS, NM = kPullNM, HS = kPairHS, TR = 8;
+  constexpr int kOps1 = RB + 2;                      // stage 1 per iteration: RB row DMAs, 1 multiplier DMA, 1 atomic
+  constexpr int kAhead1 = (NS - 1) * kOps1;          // younger than the atomic of iteration i - NS at iteration i's wait
+  constexpr int kOps2 = RB + 1;                      // stage 2 per iteration: 1 multiplier DMA, RB stores
+  constexpr int kAhead2 = RB + (NS - 1) * kOps2;     // younger than the multiplier DMA of batch i (issued at i - NS)
+  __shared__ __attribute__((aligned(16))) char sm[2 * kPairBytes];
+  const int np = ring_count(ring, 2 * K, kmax, reinterpret_cast<int*>(sm));
+  __syncthreads();   // everyone has read the count before anything lands on it
+  if (np <= K) return;   // 0..32 pivots: the generic kernels behind this launch take the block (two passes)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int pair = wave & 1, stage = wave >> 1;
+  // the grid is G workgroups per PAIR of sub-strips; XCD x walks the pairs shifted by x * npairs / 8 (see k_sweep32_pull)
+  const int npairs = nstrips_full * 2;
+  const int pp = (npairs % 8 == 0)
+                     ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(npairs / 8)) % (unsigned)npairs)
+                     : (int)(blockIdx.x % (unsigned)npairs);
+  const int sub = pp * 2 + pair;
+  const int nbt = m_local / RB;
+  unsigned* const ctr = tickets + sub * 32;
+  const int64_t row_bytes = ld * 8;
+  const int64_t batch_bytes = RB * row_bytes;
+  char* const dst_base = reinterpret_cast<char*>(A + sub * 128);
+  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + sub * 128) : dst_base;
+  const uint32_t off0 = lane * 16u;
+  const uint32_t rb32 = (uint32_t)row_bytes;
+  // LDS of the pair: stage 1's batch slots and multiplier slots, the hand-over slots, stage 2's multiplier slots, words
+  char* const base = sm + pair * kPairBytes;
+  char* const stage1 = base;
+  char* const mult1 = stage1 + NS * kDmaSlotBytes;
+  char* const hand = base + kPullWaveBytes;
+  char* const mult2 = hand + HS * kDmaSlotBytes;
+  int* const words = reinterpret_cast<int*>(mult2 + NM * 1024);   // [0] seq, [1] used, [2] done, [8 ..] ticket ring
+  int* const tring = words + 8;
+  if (threadIdx.x < 128) {   // both pairs' words: nothing handed over, nothing taken, not done
+    int* const w = reinterpret_cast<int*>(sm + (threadIdx.x >> 6) * kPairBytes + kPullWaveBytes + HS * kDmaSlotBytes + NM * 1024);
+    if (lane < 8 + TR) w[lane] = lane >= 8 ? INT_MAX : 0;
+  }
+  __syncthreads();
+  // the wave's 32 pivot-row slices: pivots 0..31 (stage 1) or 32..63 (stage 2; +0 for the identity steps beyond np)
+  d2 pr[K];
+  {
+    const double* const pbase = prow_ring + ((int64_t)(stage * K) * ld + sub * 128 + 2 * lane);
+    const int npl = np - stage * K;   // valid pivots of this stage
+#pragma unroll
+    for (int s = 0; s < K; ++s) {
+      pr[s] = *reinterpret_cast<const d2*>(pbase + (int64_t)s * ld);
+      if (s >= npl) pr[s] = d2{0.0, 0.0};   // uniform
+    }
+  }
+
+  // ONE loop for both stages (one instance of the 32-step arithmetic: two copies made the register allocator spill the
+  // slices); what differs per stage sits in small wave-uniform branches:
+  //                    stage 1 (pivots 0..31)                         stage 2 (pivots 32..63)
+  //   ticket of i+3    its own atomic, published in the LDS ring      read from the LDS ring
+  //   batch i from     its LDS-DMA slot (rows of the tableau)         the hand-over slot, once seq > i
+  //   LDS-DMA issued   rows + multipliers of batch i+3, the atomic    multipliers of batch i+3
+  //   batch i goes     into the hand-over slot (once used > i - HS)   to memory (nt stores)
+  const bool s1 = stage == 0;
+  const uint32_t lds_rows = lds_addr_of(stage1), lds_mult = lds_addr_of(s1 ? mult1 : mult2);
+  const char* const in_slots = s1 ? stage1 : hand;
+  const char* const mult_slots = s1 ? mult1 : mult2;
+  auto issue = [&](int t, int it) {   // batch t becomes iteration it's
+    const uint32_t lm = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_mult + (uint32_t)((it % NM) * 1024)));
+    const char* const mbase = reinterpret_cast<const char*>(col_packed) + (int64_t)t * 2048 + (s1 ? 0 : 1024);
+    if (s1) {
+      dma_batch4m<NT>(src_base + (int64_t)t * batch_bytes, off0, off0 + rb32, off0 + 2 * rb32, off0 + 3 * rb32,
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_rows + (uint32_t)((it % NS) * kDmaSlotBytes))),
+                      mbase, lm);
+    } else {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(off0), "s"(mbase), "s"(lm) : "memory");
+    }
+  };
+  static_assert(HS == NS, "one unrolled loop: batch slot and hand-over slot of iteration i are both i % NS");
+  unsigned tk[NS];   // (stage 1 only)
+  int bq[NS + 1];   // bq[k]: the batch of iteration i + k (>= nbt: none)
+  if (s1) {
+#pragma unroll
+    for (int u = 0; u < NS; ++u) ticket_pull(tk[u], ctr);
+    dma_wait<0>();
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      bq[u] = ticket_take(tk[u]);
+      if (lane == 0) lds_word_store(&tring[u], bq[u]);
+      if (bq[u] < nbt) issue(bq[u], u);
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) ticket_pull(tk[u], ctr);
+    dma_wait<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tickets 0..NS-1 are in the ring: stage 2 may start
+  } else {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      bq[u] = lds_word_load(&tring[u]);
+      if (bq[u] < nbt) issue(bq[u], u);
+    }
+    dma_wait<0>();
+  }
+  int full = 0;   // consecutive most recent iterations that issued all their operations
+#pragma unroll 1
+  for (int i0 = 0;; i0 += NS) {
+    if (bq[0] >= nbt) break;   // tickets only grow: nothing is left for this pair
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int i = i0 + u;
+      const int t = bq[0];
+      if (t < nbt) {   // uniform
+        if (s1) {
+          if (full >= NS) dma_wait<kAhead1>(); else if (i >= NS) dma_wait<0>();
+          bq[NS] = ticket_take(tk[u]);
+          if (lane == 0) lds_word_store(&tring[(i + NS) % TR], bq[NS]);   // (its previous tenant was read long ago)
+        } else {
+          unsigned spins = 0;
+          while (lds_word_load(&words[0]) < i + 1) {   // batch i handed over?
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 26)) break;   // (never in a healthy run: keeps a bug from hanging the device)
+          }
+          if (full >= NS) dma_wait<kAhead2>(); else if (i >= NS) dma_wait<0>();
+          bq[NS] = lds_word_load(&tring[(i + NS) % TR]);   // published by stage 1 in ITS iteration i: it is past that
+        }
+        const char* const slot = in_slots + u * kDmaSlotBytes + lane * 16;
+        d2 x[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) x[r] = *reinterpret_cast<const d2*>(slot + r * 1024);
+        const bool more = bq[NS] < nbt;
+        if (s1) {
+          if (more) issue(bq[NS], i + NS);   // refills the slot just read (the statement waits for the reads first)
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          ticket_pull(tk[u], ctr);
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) lds_word_store(&words[1], i + 1);   // the hand-over slot may be refilled
+          if (more) issue(bq[NS], i + NS);
+        }
+        full = more ? full + 1 : 0;
+        sweep_apply_lin<K, RB, RB>(x, pr, reinterpret_cast<const double*>(mult_slots + (i % NM) * 1024));
+        if (s1) {
+          if (i >= HS) {   // slot i % HS is free once stage 2 has taken batch i - HS
+            unsigned spins = 0;
+            while (lds_word_load(&words[1]) < i - HS + 1) {
+              __builtin_amdgcn_s_sleep(1);
+              if (++spins > (1u << 26)) break;
+            }
+          }
+          char* const hs = hand + u * kDmaSlotBytes + lane * 16;
+#pragma unroll
+          for (int r = 0; r < RB; ++r) *reinterpret_cast<d2*>(hs + r * 1024) = x[r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) lds_word_store(&words[0], i + 1);
+        } else {
+          char* const out = dst_base + (int64_t)t * batch_bytes;   // uniform
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            d2* q = reinterpret_cast<d2*>(out + (off0 + (uint32_t)r * rb32));
+            if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
+          }
+        }
+      } else {
+        bq[NS] = INT_MAX;
+      }
+#pragma unroll
+      for (int k = 0; k < NS; ++k) bq[k] = bq[k + 1];
+    }
+  }
+  dma_wait<0>();   // stage 1's pending ticket atomics write registers of this wave: let them land before it ends
 }
 
 // ---- 64 pivots per pass: two stages of 32 inside one workgroup ------------------------------------------------------
@@ -2977,7 +3180,12 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 1, R.col_packed, R.tickets);
   if (R.tickets && R.col_packed) {   // m_local = 0: the first ticket already names nothing
     LPX_EACH_NT_OOP(LPX_PRE_PULL)
-    hipLaunchKernelGGL(k_pack_multipliers, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed);
+    hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed);
+    hipLaunchKernelGGL(k_pack_multipliers<64>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed);
+#define LPX_PRE_PULL64(NT_, OOP_) \
+    hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
+    LPX_EACH_NT_OOP(LPX_PRE_PULL64)
+#undef LPX_PRE_PULL64
   }
 #undef LPX_PRE_PULL
 #undef LPX_PRE_DMA
@@ -3091,7 +3299,7 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, nstrips_full)));
   (void)hipMemsetAsync(R.tickets, 0, (size_t)nstrips_full * 4 * 128, s);
-  hipLaunchKernelGGL(k_pack_multipliers, dim3((nbt + 7) / 8), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed);
+  hipLaunchKernelGGL(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed);
   const dim3 grid(nstrips_full * G), block(256);
 #define LPX_LAUNCH_PULL(NT_, OOP_)                                                                                \
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
@@ -3099,6 +3307,25 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
   if (A_src) { if (nt) LPX_LAUNCH_PULL(true, true); else LPX_LAUNCH_PULL(false, true); }
   else { if (nt) LPX_LAUNCH_PULL(true, false); else LPX_LAUNCH_PULL(false, false); }
 #undef LPX_LAUNCH_PULL
+}
+
+// blocks of 33..64: pairs of waves, batches pulled from the same per-sub-strip counters; G workgroups (two pairs each)
+// per pair of sub-strips
+static void launch_sweep64_pull(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
+                                hipStream_t s, int slots = 512) {
+  const int nstrips_full = (int)(B.ld / 512);
+  const int npairs = nstrips_full * 2;
+  const int nbt = m_local / 4;
+  const int G = std::max(1, std::min(nbt, slots / std::max(1, npairs)));
+  (void)hipMemsetAsync(R.tickets, 0, (size_t)nstrips_full * 4 * 128, s);
+  hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed);
+  const dim3 grid(npairs * G), block(256);
+#define LPX_LAUNCH_PULL64(NT_, OOP_)                                                                              \
+  hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
+                     nstrips_full, R.col_packed, R.tickets)
+  if (A_src) { if (nt) LPX_LAUNCH_PULL64(true, true); else LPX_LAUNCH_PULL64(false, true); }
+  else { if (nt) LPX_LAUNCH_PULL64(true, false); else LPX_LAUNCH_PULL64(false, false); }
+#undef LPX_LAUNCH_PULL64
 }
 
 static void launch_sweep64_pipe(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
@@ -3169,6 +3396,7 @@ const char* sweep_kernel_name(int code) {
     case kSweepPipe64: return "k_sweep64_pipe";
     case kSweepDma: return "k_sweep32_dma";
     case kSweepPull: return "k_sweep32_pull";
+    case kSweepPull64: return "k_sweep64_pull";
     default: return "";
   }
 }
@@ -3202,19 +3430,27 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     // m not a multiple of 4) takes two passes of the generic kernel: slots 0..31 (out of place when asked), then
     // slots 32.. in place on the result.  An entry's update reads ring values only, so the split changes nothing.
     const int nstrips_full = (int)(B.ld / 512);
-    const bool pipe = K == 64 && m_local % 4 == 0 && nstrips_full >= 1;
+    const bool geom = m_local % 4 == 0 && nstrips_full >= 1;
+    const bool pull = geom && form != 1 && R.tickets && R.col_packed;   // round 3: blocks of 33..64 valid pivots
+    const bool pipe = geom && !pull && K == 64;                         // round 2: full blocks of 64 only
     int rows64 = 0;
-    if (pipe) {
+    if (pull) {
+      launch_sweep64_pull(B, R, m_local, K, nt, A_src, s, 2 * cus);
+      rows64 = 4;
+    } else if (pipe) {
       rows64 = rows_per_wg > 0 ? std::max(4, rows_per_wg / 4 * 4) : choose_pipe_rows(m_local, nstrips_full, cus);
       while (rows64 > 4 && (int64_t)rows64 * B.ld * 8 >= (int64_t)1 << 32) rows64 -= 4;  // 32-bit offsets
       launch_sweep64_pipe(B, R, m_local, K, rows64, nt, A_src, s);
     }
+    // what the one-pass kernel does not take (the partial last strip; a block with fewer valid pivots than it wants:
+    // < 33 for the pull form, < 64 for the two-stage pipe) goes through two passes of the generic kernel
+    const int complement = pull ? 34 : (pipe ? 65 : 0);
     int rows = choose_sweep_rows(m_local, B.ld, 32, cus);
     while (rows > kSweepChunk && (int64_t)rows * B.ld * 8 >= (int64_t)1 << 32) rows -= kSweepChunk;
-    launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, pipe ? 65 : 0, 0);
-    launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, pipe ? 65 : 0, 32);
-    rows_per_wg = pipe ? rows64 : rows;
-    used = pipe ? kSweepPipe64 : kSweepMulti;
+    launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, complement, 0);
+    launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, complement, 32);
+    rows_per_wg = (pull || pipe) ? rows64 : rows;
+    used = pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti);
 #ifndef LPX_STEADY_PARTIAL
 #define LPX_STEADY_PARTIAL 1
 #endif

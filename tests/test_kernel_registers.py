@@ -140,7 +140,7 @@ def test_no_register_copy_reads_a_hand_issued_load_before_its_wait(device_asm, k
 
 
 # ---- round 3: the LDS-DMA sweep kernels -------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", ["k_sweep32_dma", "k_sweep32_pull"])
+@pytest.mark.parametrize("kernel", ["k_sweep32_dma", "k_sweep32_pull", "k_sweep64_pull"])
 def test_lds_dma_sweep_kernels_have_no_scratch(device_asm, kernel):
     """Their tableau loads land in LDS, not in registers, but the pivot-row slices (128 VGPRs) must stay in registers
     and two workgroups must fit a CU: no scratch, no AGPRs, at most 256 VGPRs, LDS <= 80 KiB."""
@@ -153,12 +153,13 @@ def test_lds_dma_sweep_kernels_have_no_scratch(device_asm, kernel):
     assert len(lds) == 4 and all(int(x) <= 80 * 1024 for x in lds), lds
 
 
-def test_pulled_tickets_are_not_touched_before_they_are_taken(device_asm):
-    """k_sweep32_pull's only hand-issued operation with a register destination is the ticket atomic.  Between the asm
+@pytest.mark.parametrize("kernel", ["k_sweep32_pull", "k_sweep64_pull"])
+def test_pulled_tickets_are_not_touched_before_they_are_taken(device_asm, kernel):
+    """The pull kernels' only hand-issued operation with a register destination is the ticket atomic.  Between the asm
     statement that issues it and the v_readfirstlane that takes the ticket (behind a hand-written s_waitcnt vmcnt and
     a scheduling barrier) no compiler-generated instruction may name that register — a copy made earlier would carry
     the value from before the atomic returned (the hazard class of DESIGN.md 3a)."""
-    bodies = _kernel_bodies(device_asm, "k_sweep32_pull")
+    bodies = _kernel_bodies(device_asm, kernel)
     assert len(bodies) == 4, sorted(bodies)
     for name, lines in bodies.items():
         labels = {ln[:-1]: k for k, ln in enumerate(lines) if ln.endswith(":") and ln.startswith(".LBB")}
