@@ -1110,3 +1110,25 @@ def test_soak_repeated_runs_on_the_shape_that_exposed_the_stale_read(lps, oracle
         if not (np.array_equal(bits(got[0]), bits(want[0])) and got[3] == want[3] and list(got[4]) == list(want[4])):
             bad.append(rep)
     assert not bad, "%d of %d repetitions differ from the oracle: %s" % (len(bad), reps, bad[:20])
+
+
+@pytest.mark.parametrize("shape", [(1000, 2100), (4100, 1024), (8, 512), (2052, 4100)])
+@pytest.mark.parametrize("block,kernel", [(21, "k_sweep32_pull"), (32, "k_sweep32_pull"), (40, "k_sweep64_pull"),
+                                          (64, "k_sweep64_pull")])
+def test_pulled_sweep_kernels_on_ragged_shapes(lps, oracle, shape, block, kernel):
+    """The ticket-pulling sweep kernels (one wave / one pair of waves per 128-column sub-strip worker) on shapes with a
+    partial last strip, a last batch count that is not a multiple of anything, fewer batches than workers, and blocks
+    that are only partly filled (21 of 32, 40 of 64 steps are real, the rest identities): bit-exact vs the fp64
+    oracle after every budget; the engine must report the kernel that is expected to have run."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=11 * m + n)
+    st = lps.LPState(A, b, c, block=block)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (block - 1, 2 * block + 5, block - 1):   # a full block of `block` decisions (block - 1 pivots + the probe)
+        status, pivots, _ = st.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget, threads=8)
+        assert (status, pivots) == (want["status"], want["pivots"]), (shape, block, budget)
+        assert_state_bits_equal(st.read(), ref.read(), "block %d budget %d of %s" % (block, budget, shape))
+    if status == 9:   # still running: the last sweep applied block - 1 >= 17 pivots
+        assert st.info()["sweep_kernel_name"] == kernel, st.info()
+    st.close()
