@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LPX_ABI_VERSION 2
+#define LPX_ABI_VERSION 3
 
 /* Status codes.  One per exception message of the reference; the host shim maps them back
  * to the exact exception class + message because the reference's tests assert on the text. */
@@ -135,7 +135,8 @@ typedef enum lpx_option {
   LPX_OPT_UPDATE_ROWS = 12,   /* one-pass update: rows per workgroup (even, 2..256)                                  */
   LPX_OPT_A2_OFFSET = 13,     /* skew between the two tableau buffers in doubles (before the second one exists)      */
   LPX_OPT_SWEEP_FORM = 14,    /* blocks of 17..32: 0 = k_sweep32_pull (LDS-DMA staging, batches pulled in address order; default), 1 = k_sweep32_steady (register staging, runs of rows), 2 = k_sweep32_dma (LDS-DMA, runs) */
-  LPX_OPT_COUNT = 15
+  LPX_OPT_MULTI_ONEHOP = 15,  /* lpx_multi: 1 = every shard ships its candidate's row with its candidate (one cross-device hop per decision instead of two); 0 (default) = candidates, then the winner's normalised row */
+  LPX_OPT_COUNT = 16
 } lpx_option;
 int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value);
 int lpx_state_get_option(const lpx_state* s, int32_t key, int64_t* value);
@@ -155,6 +156,8 @@ typedef struct lpx_state_info {
   int32_t nontemporal;          /* tableau accesses are non-temporal                                               */
   int32_t sweep_rows;           /* rows per workgroup (run length) of the last blocked sweep                       */
   int32_t sweep_kernel;         /* the kernel that swept the bulk of the tableau last (lpx_sweep_kernel_name)      */
+  int32_t multi_onehop;         /* lpx_multi: 1 = the last decision launches used the one-hop exchange              */
+  int32_t reserved[3];
 } lpx_state_info;
 int lpx_state_get_info(lpx_state* s, lpx_state_info* out);
 /* Name of a lpx_state_info.sweep_kernel code as rocprofv3 prints it ("k_sweep32_dma", "k_update_tiles", ...; "" = none). */

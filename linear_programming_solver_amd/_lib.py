@@ -16,7 +16,7 @@ PRICING = {"reference": 0, "first-positive": 0, "dantzig": 1, 0: 0, 1: 1}
 # lpx_option (include/lpx.h)
 OPTIONS = {"block": 0, "chain": 1, "overlap": 2, "overlap_serial": 3, "overlap_mask": 4, "chain_wgs": 5,
            "chain_fences": 6, "sweep_rows": 7, "nt": 8, "batch": 9, "chain_trace": 10, "update_u": 11,
-           "update_rows": 12, "a2_offset": 13, "sweep_form": 14}
+           "update_rows": 12, "a2_offset": 13, "sweep_form": 14, "multi_onehop": 15}
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
@@ -43,7 +43,7 @@ class StateInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "block", "chain_wgs", "chain_wgs_requested", "chain_resident_max", "chain_blocks_per_cu",
         "chain_stream_masked", "chain_xcd_mask", "sweep_xcd_mask", "overlapped", "nontemporal", "sweep_rows",
-        "sweep_kernel")]
+        "sweep_kernel", "multi_onehop", "reserved0", "reserved1", "reserved2")]
 
 
 class SolveOptions(C.Structure):

@@ -75,6 +75,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_ROWS_PER_TILE", 2, 2, 256},       // LPX_OPT_UPDATE_ROWS
     {"LPX_A2_OFFSET", 512, 0, 1 << 20},     // LPX_OPT_A2_OFFSET
     {"LPX_SWEEP_FORM", 0, 0, 2},            // LPX_OPT_SWEEP_FORM
+    {"LPX_MULTI_ONEHOP", 0, 0, 1},          // LPX_OPT_MULTI_ONEHOP
 };
 
 static const int64_t* env_defaults() {
@@ -155,6 +156,8 @@ static void free_block_ring(lpx_state* s) {
   (void)hipFree(s->R.col_packed);
   (void)hipFree(s->R.mg_mail);
   (void)hipFree(s->R.mg_arrive);
+  (void)hipFree(s->R.mg_candrow);
+  (void)hipFree(s->R.mg_arrive2);
   (void)hipFree(s->d_cand);
   s->R = lpxk::BlockRing{};
   s->d_cand = nullptr;
@@ -503,6 +506,14 @@ static int build_block_ring(lpx_state* s) {
   HIP_TRY(peer_visible_malloc(s, (void**)&s->R.mg_arrive, lpxk::kChainMaxWgs * sizeof(unsigned long long)));
   HIP_TRY(hipMemsetAsync(s->R.mg_mail, 0, 2 * lpxk::kMaxDevices * 32, s->stream));
   HIP_TRY(hipMemsetAsync(s->R.mg_arrive, 0, lpxk::kChainMaxWgs * sizeof(unsigned long long), s->stream));
+  if (s->m != s->m_global || s->peer_written || s->multi_shard) {   // a shard of an lpx_multi: the one-hop exchange buffers
+    const size_t rows_bytes = 2 * (size_t)lpxk::kMaxDevices * (size_t)s->B.ld * sizeof(double);
+    const size_t words_bytes = 2 * (size_t)lpxk::kMaxDevices * lpxk::kChainMaxWgs * sizeof(unsigned long long);
+    HIP_TRY(peer_visible_malloc(s, (void**)&s->R.mg_candrow, rows_bytes));
+    HIP_TRY(peer_visible_malloc(s, (void**)&s->R.mg_arrive2, words_bytes));
+    HIP_TRY(hipMemsetAsync(s->R.mg_candrow, 0, rows_bytes, s->stream));
+    HIP_TRY(hipMemsetAsync(s->R.mg_arrive2, 0, words_bytes, s->stream));
+  }
   HIP_TRY(hipMalloc((void**)&s->R.col, K * (size_t)mp * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.col0, K * (size_t)mp * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.row0, K * (size_t)s->B.ld * sizeof(double)));

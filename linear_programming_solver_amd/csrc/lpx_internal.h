@@ -48,6 +48,7 @@ struct lpx_state {
   lpx_state_info info{};            // what the last loop actually did (lpx_state_get_info)
   int chain_nb_last = 0;            // decisions of the last k_block_chain launch (chain trace)
   bool peer_written = false;        // a shard of an lpx_multi on several devices: buffers that peers store into
+  bool multi_shard = false;     // a shard of an lpx_multi (also with a single shard / all shards on one GPU)
                                     // (pivot-row ring, mailbox, arrival words) are allocated fine-grained
   lpxk::BlockRing R{};
   int chain_seq = 0;                // k_block_chain launches so far (its two barrier counters alternate)

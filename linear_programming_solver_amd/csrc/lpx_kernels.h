@@ -105,6 +105,8 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   // shards of an lpx_multi only (else NULL): written by the peers' decision kernels
   void* mg_mail;                   // MgMail[2][kMaxDevices]
   unsigned long long* mg_arrive;   // [kChainMaxWgs]
+  double* mg_candrow;              // one-hop form: candidate rows [2][kMaxDevices][ld]
+  unsigned long long* mg_arrive2;  // one-hop form: arrival words of the candidate rows [2][kMaxDevices][kChainMaxWgs]
 };
 constexpr int kChainMaxWgs = 256;   // <= one workgroup per CU: the whole grid is resident
 constexpr int kMaxDevices = 8;      // row-block shards of one lpx_multi (the GPUs of one node)
@@ -127,6 +129,9 @@ struct MgPeers {
   void* mail[kMaxDevices];                 // MgMail[2][kMaxDevices] (32-byte records) of every shard
   double* prow[kMaxDevices];               // base of every shard's pivot-row ring (BlockRing::prow)
   unsigned long long* arrive[kMaxDevices]; // arrival words [kChainMaxWgs] of every shard
+  int onehop;                              // 1: every shard ships its candidate's ROW with the candidate (one hop per decision)
+  double* candrow[kMaxDevices];            // candidate rows [2][kMaxDevices][ld] of every shard
+  unsigned long long* arrive2[kMaxDevices];// their arrival words [2][kMaxDevices][kChainMaxWgs]
 };
 // fences: grid-barrier form (bit 0 release fence, bit 1 acquire fence); trace: record phase timestamps in R.chain_dbg.
 // mg != NULL: the launch of one shard of an lpx_multi (m = the shard's rows); every shard must use the same wgs.

@@ -811,6 +811,13 @@ __device__ __forceinline__ double from32(unsigned lo, unsigned hi) { return __hi
 //   (2) the normalised pivot row: the shard that owns the leaving row computes it (thread = column) and stores every
 //       value into every device's replica of the ring ((n+1) doubles = 128 KiB at n = 16384, 7 links in parallel),
 //       then each of its workgroups raises its arrival word on every device.
+// One-hop form (LPX_OPT_MULTI_ONEHOP, off by default — like the rest of this path it has only ever run with all shards
+// on one GPU): a decision above costs two DEPENDENT cross-device hops (candidates, then the winner's row).  Instead
+// every shard computes the row of its OWN candidate (thread = column, pending pivots applied) before it knows whether
+// it wins, stores it un-normalised into slot `dev` of every device's candidate-row buffer together with the candidate
+// record, and raises per-workgroup arrival words; every device then picks the winner from its mailbox, waits for THAT
+// shard's arrival words only and normalises the row itself (x / p is the same correctly rounded division everywhere).
+// One hop per decision, 128 KiB x 7 links per device of wire (~1 us), n_dev times the row arithmetic in parallel.
 // Stores to peers and loads of peer-written data are system-scope (sc0 sc1: write-through / cache-bypassing) and a
 // tag or arrival word is stored only after the storing waves have drained (s_waitcnt vmcnt(0)) and met; with
 // fences bit 0 / 1 a system-scope release / acquire fence is added around every exchange (the default across real
@@ -963,6 +970,10 @@ struct ChainArgs {
   MgMail* mail_peer[kMaxDevices];            // every shard's mailbox [2][kMaxDevices] (peer-mapped); [dev] = own
   double* prow_peer[kMaxDevices];            // every shard's replica of this block's pivot-row ring half
   unsigned long long* arrive_peer[kMaxDevices];  // every shard's arrival words [kChainMaxWgs]
+  // one-hop form (onehop != 0): every shard ships the ROW of its own candidate with the candidate, see k_block_chain_t
+  int onehop;
+  double* candrow_peer[kMaxDevices];             // every shard's candidate rows [2][kMaxDevices][ld]
+  unsigned long long* arrive2_peer[kMaxDevices]; // every shard's arrival words of the candidate rows [2][kMaxDevices][kChainMaxWgs]
 };
 
 // KB: capacity of one ring half seen by the launch (32, or 64 for blocks of more than 32 pivots — the same code with
@@ -1184,6 +1195,89 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     RatioRow w = rr_block_min(mine, sh_rr);
     if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
     __syncthreads();
+    const bool window = !P.dantzig && ld >= 256;  // every thread of workgroup 0 then owns one of the slots 0..255
+    // Column ownership: with the hand-off, workgroup 0 owns slots 0..255 and nothing else (it is on everybody's
+    // critical path), the other workgroups share the rest; fixed for the launch, as the private copies require.
+    const bool solo0 = window && G > 1;
+    const int jstep = solo0 ? T - 256 : T;
+    const bool onehop = MG && P.onehop != 0;
+    // the row `ll` (local index) of the current tableau at column j: the stale row run through the pending pivots,
+    // restarted at pivot rb if that one left through the same row; needs sh_cs / sh_dv / sh_e of row ll
+    auto row_value = [&](int j, int ll, int rb, int fo_b, int fn_b) -> double {
+      const double* rowl = A + (int64_t)ll * ld;
+      const double* src_x = rb < 0 ? &rowl[j]
+                                   : (rb < KB ? &P.own_prow_o[(int64_t)rb * ld + j] : &P.own_prow[(int64_t)(rb - KB) * ld + j]);
+      double x = *src_x;
+      double prv[KB], prvo[KB];  // this thread's own stores, live chunks only (see phase A)
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8)
+        if (LPX_CHAIN_LIVE(r0, fo_b, n_old)) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) prvo[r0 + q] = P.own_prow_o[(int64_t)(r0 + q) * ld + j];
+        }
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8)
+        if (LPX_CHAIN_LIVE(r0, fn_b, s)) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) prv[r0 + q] = P.own_prow[(int64_t)(r0 + q) * ld + j];
+        }
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(0, r0, fo_b, n_old, prvo)
+      st_agent(&P.row0[(int64_t)s * ld + j], x);  // the row as the sweep of this block will read it (see col0)
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(KB, r0, fn_b, s, prv)
+      return x;
+    };
+    // per pending pivot u: col_u[ll] and -(col_u[ll] / p_u) into LDS, the restart pivot of row ll (LDS index or -1)
+    auto row_params = [&](bool valid_row, int ll, int l_global) -> int {
+      if (tid < 2 * KB) {
+        const int r = tid & (KB - 1);
+        const bool old = tid < KB;
+        const bool valid = valid_row && (old ? r < n_old : r < s);
+        bool same = false;
+        if (valid) {
+          const double csv = ld_agent((old ? P.col_o : P.col) + (int64_t)r * mp + ll);
+          sh_cs[tid] = csv;
+          sh_dv[tid] = -__ddiv_rn(csv, sh_p[tid]);
+          same = sh_l[tid] == l_global;
+        }
+        const unsigned long long mask = __ballot(same);
+        if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
+      }
+      __syncthreads();
+      return chain_restart<KB>(sh_mask);
+    };
+    if constexpr (MG) {
+      if (onehop) {
+        // ---- this shard's candidate row goes to every device BEFORE anybody knows the winner
+        const int mslot = (P.mail_slot0 + s) & 1;
+        const bool have = w.row != INT_MAX;          // (identical in every workgroup of this shard)
+        const int lc = have ? w.row - row0 : 0;
+        const int rbc = row_params(have, lc, w.row);
+        const int fo_c = rbc < 0 ? 0 : (rbc < KB ? rbc + 1 : n_old);
+        const int fn_c = rbc >= KB ? rbc - KB + 1 : 0;
+        if (have) {
+          const int64_t base = (int64_t)(mslot * kMaxDevices + P.dev) * ld;
+          for (int j = gid; j < (int)ld; j += (solo0 && blockIdx.x == 0) ? (int)ld : jstep) {
+            const double x = j < n ? row_value(j, lc, rbc, fo_c, fn_c) : 0.0;
+            for (int d = 0; d < P.n_dev; ++d) st_sys(&P.candrow_peer[d][base + j], x);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          if (P.fences & 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          for (int d = 0; d < P.n_dev; ++d)
+            __hip_atomic_store(&P.arrive2_peer[d][(int64_t)(mslot * kMaxDevices + P.dev) * kChainMaxWgs + blockIdx.x],
+                               (unsigned long long)xtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();   // sh_cs / sh_dv / sh_mask are rewritten below
+      }
+    }
+    int dstar = 0;   // one-hop: the shard whose candidate won
     if constexpr (MG) {
       // The two mailbox slots alternate with the decisions of the whole LOOP, not of the launch: a device may be one
       // decision ahead of a peer — also across the boundary between two launches (a block of odd length would reuse
@@ -1227,8 +1321,10 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
       }
       w = rr_block_min(theirs, sh_rr);
       if (sh_fail) { if (lead) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
-      if (w.row != INT_MAX && tid < P.n_dev && theirs.row == w.row) { sh_win[0] = theirs_a; sh_win[1] = theirs_b; }
+      if (w.row != INT_MAX && tid < P.n_dev && theirs.row == w.row) { sh_win[0] = theirs_a; sh_win[1] = theirs_b; sh_restart = tid; }
       __syncthreads();
+      dstar = sh_restart;   // (only read in the one-hop form, and only when there is a winner)
+      __syncthreads();      // sh_restart is reused further down
     }
     if (w.row == INT_MAX || !(w.ratio < kInf)) {  // getLeaving() == -1: unbounded
       if (lead) {
@@ -1255,22 +1351,8 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     // On shards only the device that holds row l computes it; the others receive the normalised row (see below).
     const bool owner = !MG || (l >= row0 && l < row0 + m);
     const int ll = l - row0;  // local index of the leaving row on its owner
-    if (tid < 2 * KB) {
-      const int r = tid & (KB - 1);
-      const bool old = tid < KB;
-      const bool valid = owner && (old ? r < n_old : r < s);
-      bool same = false;
-      if (valid) {
-        const double csv = ld_agent((old ? P.col_o : P.col) + (int64_t)r * mp + ll);
-        sh_cs[tid] = csv;
-        sh_dv[tid] = -__ddiv_rn(csv, sh_p[tid]);
-        same = sh_l[tid] == l;
-      }
-      const unsigned long long mask = __ballot(same);
-      if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
-    }
-    __syncthreads();
-    const int rb = chain_restart<KB>(sh_mask);
+    int rb = -1;
+    if (!onehop) rb = row_params(owner, ll, l);
     const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
     const int fn_b = rb >= KB ? rb - KB + 1 : 0;
 #ifdef LPX_CHAIN_DBG2   // diagnostic build: stamp 1 = leaving row known and its column values fetched
@@ -1279,10 +1361,24 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     const double bl = __ddiv_rn(raw_b, p);                                         // :146
     const double inv_p = __ddiv_rn(1.0, p);                                        // :139
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
-    const bool window = !P.dantzig && ld >= 256;  // every thread of workgroup 0 then owns one of the slots 0..255
-    const double* rowl = A + (int64_t)(owner ? ll : 0) * ld;
+    const double* cand_row = nullptr;   // one-hop: the winner's un-normalised row in THIS device's buffer
     if constexpr (MG) {
-      if (!owner) {
+      if (onehop) {
+        // wait until every workgroup of the WINNING shard has stored its columns of the candidate row here
+        const int mslot = (P.mail_slot0 + s) & 1;
+        if (tid < G) {
+          const unsigned long long* aw = &P.arrive2_peer[P.dev][(int64_t)(mslot * kMaxDevices + dstar) * kChainMaxWgs + tid];
+          unsigned spins = 0;
+          while (__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)xtag) {
+            LPX_BARRIER_SLEEP;
+            if (++spins > (1u << 22)) { sh_fail = 5 + 16 * tid; break; }   // 5: the winner's candidate-row arrival word
+          }
+          if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        }
+        __syncthreads();
+        if (sh_fail) { if (lead) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
+        cand_row = P.candrow_peer[P.dev] + (int64_t)(mslot * kMaxDevices + dstar) * ld;
+      } else if (!owner) {
         // wait until every workgroup of the owner has stored its columns of the normalised row into THIS device's
         // replica of the ring (one arrival word per owner workgroup, raised after its stores have drained)
         if (tid < G) {
@@ -1298,46 +1394,24 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         if (sh_fail) { if (lead) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
       }
     }
-    // Column ownership: with the hand-off, workgroup 0 owns slots 0..255 and nothing else (it is on everybody's
-    // critical path), the other workgroups share the rest; fixed for the launch, as the private copies require.
-    const bool solo0 = window && G > 1;
-    const int jstep = solo0 ? T - 256 : T;
+    const bool local_row = owner || onehop;   // this device computes the normalised row itself
     for (int j = gid; j < (int)ld; j += (solo0 && blockIdx.x == 0) ? (int)ld : jstep) {
       double x = 0.0;
       const double cj = ld_agent(&P.c[j]);  // this thread's own store (or the initial value)
-      if (j < n && owner) {
-        const double* src_x = rb < 0 ? &rowl[j]
-                                     : (rb < KB ? &P.own_prow_o[(int64_t)rb * ld + j] : &P.own_prow[(int64_t)(rb - KB) * ld + j]);
-        x = *src_x;
-        double prv[KB], prvo[KB];  // this thread's own stores, live chunks only (see phase A)
-#pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8)
-          if (LPX_CHAIN_LIVE(r0, fo_b, n_old)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) prvo[r0 + q] = P.own_prow_o[(int64_t)(r0 + q) * ld + j];
-          }
-#pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8)
-          if (LPX_CHAIN_LIVE(r0, fn_b, s)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) prv[r0 + q] = P.own_prow[(int64_t)(r0 + q) * ld + j];
-          }
-#pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(0, r0, fo_b, n_old, prvo)
-        st_agent(&P.row0[(int64_t)s * ld + j], x);  // the row as the sweep of this block will read it (see col0)
-#pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(KB, r0, fn_b, s, prv)
+      if (j < n) {
+        if (onehop) x = ld_sys(&cand_row[j]);
+        else if (owner) x = row_value(j, ll, rb, fo_b, fn_b);
       }
       double cn, pr;
       if (j == e) {
         pr = inv_p;
         cn = -__ddiv_rn(pc, p);                                                    // :172
       } else {
-        pr = owner ? __ddiv_rn(x, p) : ld_sys(&P.prow[(int64_t)s * ld + j]);       // :144 (the owner's value)
+        pr = local_row ? __ddiv_rn(x, p) : ld_sys(&P.prow[(int64_t)s * ld + j]);   // :144 (the owner's value)
         cn = __dsub_rn(cj, __dmul_rn(pc, pr));                                     // :177
       }
       if constexpr (MG) {
-        if (owner) {  // broadcast: the value goes into every other device's replica of the ring
+        if (owner && !onehop) {  // broadcast: the value goes into every other device's replica of the ring
           for (int d = 0; d < P.n_dev; ++d)
             if (d != P.dev) st_sys(&P.prow_peer[d][(int64_t)s * ld + j], pr);
         }
@@ -1365,7 +1439,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
       }
     }
     if constexpr (MG) {
-      if (owner && P.n_dev > 1) {  // this workgroup's columns are on their way to every peer: drain, meet, signal
+      if (owner && !onehop && P.n_dev > 1) {  // this workgroup's columns are on their way to every peer: drain, meet, signal
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -3129,10 +3203,13 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   if (mg) {
     P.shard_row0 = mg->row0; P.m_global = mg->m_global; P.n_dev = mg->n_dev; P.dev = mg->dev;
     P.mail_slot0 = mg->mail_slot0;
+    P.onehop = mg->onehop;
     for (int d = 0; d < mg->n_dev && d < kMaxDevices; ++d) {
       P.mail_peer[d] = reinterpret_cast<MgMail*>(mg->mail[d]);
       P.prow_peer[d] = mg->prow[d] + ho * B.ld;   // the same ring half on every shard
       P.arrive_peer[d] = mg->arrive[d];
+      P.candrow_peer[d] = mg->candrow[d];
+      P.arrive2_peer[d] = mg->arrive2[d];
     }
     if (wide) hipLaunchKernelGGL((k_block_chain_t<true, 64>), dim3(G), dim3(256), 0, s, P);
     else hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(G), dim3(256), 0, s, P);

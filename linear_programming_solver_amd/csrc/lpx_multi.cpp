@@ -99,6 +99,7 @@ int multi_create(int32_t m, int32_t n, int32_t n_cap, const double* A, int64_t l
     if (int rc = alloc_state(ml, n, n_cap, r0, m, devices[r], &s)) { multi_free(M); return rc; }
     M->sh[r] = s;
     s->peer_written = M->distinct_devices;
+    s->multi_shard = true;
     if (int rc = upload_common(s, A ? A + (int64_t)r0 * lda : nullptr, lda, b ? b + r0 : nullptr, c ? c : czero.data(), v,
                                perm, hipMemcpyHostToDevice)) {
       multi_free(M);
@@ -185,7 +186,11 @@ static lpxk::MgPeers peers_of(const lpx_multi* M, int r) {
     P.mail[d] = M->sh[d]->R.mg_mail;
     P.prow[d] = M->sh[d]->R.prow;
     P.arrive[d] = M->sh[d]->R.mg_arrive;
+    P.candrow[d] = M->sh[d]->R.mg_candrow;
+    P.arrive2[d] = M->sh[d]->R.mg_arrive2;
   }
+  P.onehop = M->sh[0]->opt[LPX_OPT_MULTI_ONEHOP] != 0 && M->sh[0]->R.mg_candrow != nullptr;
+  M->sh[r]->info.multi_onehop = P.onehop;
   return P;
 }
 

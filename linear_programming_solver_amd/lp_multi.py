@@ -112,7 +112,7 @@ class LPMulti:
         rc = self._L.lpx_multi_get_info(self._h, C.byref(out))
         if rc:
             raise_for_status(rc)
-        d = {k: getattr(out, k) for k, _ in _lib.StateInfo._fields_}
+        d = {k: getattr(out, k) for k, _ in _lib.StateInfo._fields_ if not k.startswith("reserved")}
         d["sweep_kernel_name"] = self._L.lpx_sweep_kernel_name(d["sweep_kernel"]).decode()
         return d
 

@@ -262,3 +262,50 @@ def test_c_host_without_python_in_the_compute_path(tmp_path):
     dense = [ln for ln in out.stdout.splitlines() if ln.startswith("dense rc")]
     assert len(dense) == 2 and dense[0].startswith("dense rc 0 one 150/9") and dense[1].startswith("dense rc 0 multi 150/9")
     assert dense[0].split()[5:] == dense[1].split()[5:], dense     # checksums of A, b, c and the bits of v
+
+
+# ---- the one-hop exchange (LPX_OPT_MULTI_ONEHOP): every shard ships its candidate's row with its candidate -------------
+@pytest.mark.parametrize("overlap", [1, 0], ids=["decisions-beside-sweeps", "serial"])
+@pytest.mark.parametrize("ndev", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape,block", [((64, 100), 4), ((257, 513), 16), ((1000, 260), 32), ((9, 2100), 8)])
+def test_multi_one_hop_form_matches_oracle(lps, oracle, ndev, shape, block, overlap):
+    """The same budgets as test_multi_loop_matches_oracle through the one-hop form: every shard computes the row of
+    its own candidate before the winner is known and stores it into every device's buffer; the winner's row is then
+    normalised locally everywhere.  Bit-exact against the oracle (and hence against the two-hop form)."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=11 * m + n)
+    mt = lps.LPMulti(A, b, c, devices=[0] * ndev, block=block, options={"overlap": overlap, "multi_onehop": 1})
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (1, block, 2 * block + 3, 0, 5 * block - 1, -1):
+        status, pivots, _ = mt.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget)
+        assert (status, pivots) == (want["status"], want["pivots"]), (ndev, shape, block, budget)
+        assert_state_bits_equal(mt.read(), ref.read(), "one hop, ndev %d block %d budget %d of %s" % (ndev, block, budget, shape))
+    assert mt.info()["multi_onehop"] == 1   # the launches really took the one-hop path
+    mt.close()
+
+
+@pytest.mark.parametrize("fences", [2, 3])
+def test_multi_one_hop_wide_kernels_and_ties(lps, oracle, fences):
+    """Four shards of a 4096 x 8192 tableau with the one-hop exchange at full grid width, both fence forms, serial and
+    overlapped host loops; then the all-ties LP (the winner must be the lowest GLOBAL row whichever shard holds it)."""
+    m, n = 4096, 8192
+    A, b, c = dense_lp(m, n, seed=4)
+    for devices, opts in (([0, 0, 0, 0], {"overlap": 0}), ([0, 0, 0], {})):
+        mt = lps.LPMulti(A, b, c, devices=devices, block=32, options=dict(opts, chain_fences=fences, multi_onehop=1))
+        ref = oracle.State(A, b, c, kind=oracle.FP64)
+        for budget in (100, 33):
+            status, pivots, _ = mt.simplex_loop(max_pivots=budget)
+            want = ref.simplex_loop(max_pivots=budget, threads=16)
+            assert (status, pivots) == (want["status"], want["pivots"]) == (9, budget)
+            assert_state_bits_equal(mt.read(), ref.read(), "one hop %s fences %d budget %d" % (devices, fences, budget))
+        mt.close()
+    m, n = 70, 40
+    A = np.ones((m, n)); b = np.full(m, 3.0); c = np.arange(n, 0, -1).astype(float)
+    mt = lps.LPMulti(A, b, c, devices=[0, 0, 0], block=8, options={"multi_onehop": 1, "chain_fences": fences})
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    status, pivots, _ = mt.simplex_loop()
+    want = ref.simplex_loop()
+    assert (status, pivots) == (want["status"], want["pivots"])
+    assert_state_bits_equal(mt.read(), ref.read())
+    mt.close()
