@@ -107,68 +107,6 @@ def kernel_label(block, info, ld_is_whole_strips=True):
     return name
 
 
-class PowerSampler:
-    """Board power (hwmon power1_average, microwatts) and shader clock (pp_dpm_sclk) of the GPU sampled from a host
-    thread while a loop runs: the blocked sweep sits at the package power cap (profiles/r03_power_cap.txt)."""
-
-    def __init__(self, index=0, period_s=0.004):
-        import glob
-        cards = []
-        for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
-            pw = sorted(glob.glob(dev + "/hwmon/hwmon*/power1_average")) or sorted(glob.glob(dev + "/hwmon/hwmon*/power1_input"))
-            cap = sorted(glob.glob(dev + "/hwmon/hwmon*/power1_cap"))
-            if pw:
-                cards.append((os.path.basename(os.path.realpath(dev)), pw[0], cap[0] if cap else None))
-        # the card this process computes on, by PCI address (a box may expose the hwmon nodes of all GPUs of its host)
-        want = None
-        try:
-            import torch
-            pr = torch.cuda.get_device_properties(index)
-            want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        except Exception:
-            pass
-        hit = [c for c in cards if c[0].lower() == (want or "").lower()]
-        self.card = hit[0] if hit else (cards[0] if len(cards) == 1 else None)
-        self.matched = want if hit else None
-        self.paths = [self.card[1]] if self.card else []
-        self.caps = [self.card[2]] if self.card and self.card[2] else []
-        self.index, self.period, self.samples, self._stop, self._t = 0, period_s, [], False, None
-
-    def _read(self, path):
-        try:
-            return int(open(path).read().strip()) * 1e-6
-        except Exception:
-            return None
-
-    def __enter__(self):
-        import threading
-        if self.paths:
-            path = self.paths[min(self.index, len(self.paths) - 1)]
-
-            def run():
-                while not self._stop:
-                    v = self._read(path)
-                    if v is not None:
-                        self.samples.append(v)
-                    time.sleep(self.period)
-            self._t = threading.Thread(target=run, daemon=True)
-            self._t.start()
-        return self
-
-    def __exit__(self, *a):
-        self._stop = True
-        if self._t is not None:
-            self._t.join()
-
-    def summary(self):
-        if not self.samples:
-            return None
-        cap = self._read(self.caps[min(self.index, len(self.caps) - 1)]) if self.caps else None
-        return {"samples": len(self.samples), "mean_W": float(np.mean(self.samples)), "max_W": float(np.max(self.samples)),
-                "cap_W": cap, "pci": self.matched,
-                "source": "hwmon power1_average / power1_input sampled every %.0f ms from the host" % (1e3 * self.period)}
-
-
 def parity_after(st, A, b, c, pivots, m, n, threads, max_pivots):
     """Replays `pivots` pivots of the same LP on the fp64 oracle (the checker, not the thing measured) and compares
     what the timed handle holds now: v, perm, b, c bit for bit and the position-keyed checksum of the tableau."""
@@ -319,11 +257,12 @@ def main():
                     help="skip the `onepass` object: the bandwidth-bound schedule north_star describes (one tableau pass "
                          "per pivot at N=1; two pivots per pass, the smallest block of the multi-GPU handle, at every N)")
     ap.add_argument("--onepass-steps", type=int, default=96)
+    ap.add_argument("--onehop-steps", type=int, default=256)
     ap.add_argument("--steady-steps", type=int, default=512)
     ap.add_argument("--steady-warmup", type=int, default=64)
     ap.add_argument("--no-parity", action="store_true",
                     help="skip the oracle replay that checks what the timed region computed")
-    ap.add_argument("--parity-max-pivots", type=int, default=1300,
+    ap.add_argument("--parity-max-pivots", type=int, default=1600,
                     help="largest warm-up + steps the oracle replay is run for (cfg4: ~30 ms per pivot on 16 threads)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="lpx_state_set_option on the timed handle (names: linear_programming_solver_amd._lib.OPTIONS)")
@@ -417,7 +356,7 @@ def main():
         k, v = kv.split("=", 1)
         options[k] = int(v)
 
-    def run_single(Aw, bw, cw, mw, nw, steps=None, warmup=None, st=None, done=0, power=False):
+    def run_single(Aw, bw, cw, mw, nw, steps=None, warmup=None, st=None, done=0):
         """warm-up + timed region of the single-GPU device loop on one workload; returns the measurements.
         st: continue on this handle (it has done `done` pivots) instead of uploading the tableau again."""
         Ks = K if steps is None else steps
@@ -431,16 +370,11 @@ def main():
         block = st.block()
         # one-pass form: sample every N-th row update (an event pair costs ~3 us); blocked form: few, long sweeps: all
         st.profile_enable(args.event_every if block == 1 else (1 if args.event_every > 0 else 0))
-        sampler = PowerSampler(local_rank) if power else None
         barrier()
-        if sampler:
-            sampler.__enter__()
         t0 = time.perf_counter()
         status, piv, _ = st.simplex_loop(max_pivots=Ks)
         barrier()
         elapsed = time.perf_counter() - t0
-        if sampler:
-            sampler.__exit__()
         launches, kernel_ms = st.profile_read()
         st.profile_enable(False)
         assert piv == Ks, "timed region did %d pivots instead of %d (status %d)" % (piv, Ks, status)
@@ -456,7 +390,7 @@ def main():
         avg_ms = kernel_ms / launches if launches else float("nan")
         return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms, "steps": Ks,
                 "warmup": Ws, "done": done + Ws + Ks, "pivots_per_launch": pivots_per_launch, "upload_s": t_up,
-                "info": st.info(), "power": sampler.summary() if sampler else None}
+                "info": st.info()}
 
     def measured(r, mw, nw, name, Aw, bw, cw, with_parity):
         """one measurement as an object of the JSON line: value, roofline of its sweep / row-update launch, oracle replay"""
@@ -466,8 +400,6 @@ def main():
              "value": r["steps"] / r["elapsed"], "unit": "pivots/s", "ms_per_step": 1e3 * r["elapsed"] / r["steps"],
              "steps": r["steps"], "warmup": r["warmup"], "pivots_per_sweep": r["block"],
              "roofline": roofline_block(mw, nw, r["pivots_per_launch"], r["avg_ms"], kern, r["launches"], traffic, tsrc)}
-        if r.get("power"):
-            o["board_power"] = r["power"]
         if with_parity:
             o["parity_after_timed_region"] = parity_after(r["st"], Aw, bw, cw, r["done"], mw, nw, host_cores(),
                                                           args.parity_max_pivots)
@@ -545,6 +477,24 @@ def main():
                 mt.set_option("block", info_main["block"] if info_main["block"] > 2 else 0)
             except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
                 onepass = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        onehop = None
+        if rank == 0 and err is None and nshards > 1 and not args.no_onepass:
+            # the same blocked loop with the one-hop exchange (every shard ships its candidate's row with its candidate:
+            # one cross-device hop per decision instead of two); bit-identical, so the replay below covers it as well
+            try:
+                mt.set_option("multi_onehop", 1)
+                mt.simplex_loop(max_pivots=32)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                _, piv3, _ = mt.simplex_loop(max_pivots=args.onehop_steps)
+                dt = time.perf_counter() - t1
+                extra_pivots += 32 + int(piv3)
+                onehop = {"steps": int(piv3), "value": piv3 / dt, "unit": "pivots/s", "ms_per_step": 1e3 * dt / max(1, piv3),
+                          "used": int(mt.info().get("multi_onehop", 0)),
+                          "what": "the blocked loop with LPX_OPT_MULTI_ONEHOP = 1 (opt-in; `value` is the default two-hop form)"}
+                mt.set_option("multi_onehop", 0)
+            except Exception as ex:   # noqa: BLE001
+                onehop = {"error": "%s: %s" % (type(ex).__name__, ex)}
         barrier()
         if dist is not None:
             box = [err]
@@ -566,7 +516,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return {"st": mt, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
-                "pivots_per_launch": ppl, "upload_s": t_up, "info": info, "onepass": onepass, "pivots_done": W + K + extra_pivots}
+                "pivots_per_launch": ppl, "upload_s": t_up, "info": info, "onepass": onepass, "onehop": onehop, "pivots_done": W + K + extra_pivots}
 
     fallback_reason = None
     if peer:
@@ -677,6 +627,8 @@ def main():
         line["devices_visible"] = torch.cuda.device_count()
         if peer and r1_.get("onepass") is not None:
             line["onepass"] = r1_["onepass"]
+        if peer and r1_.get("onehop") is not None:
+            line["onehop"] = r1_["onehop"]
         single = world == 1 and not sharded and not peer
         steady = {}
         want_steady = single and args.workload == "cfg4" and not args.no_steady
@@ -688,7 +640,7 @@ def main():
             if r_first["steps"] >= args.steady_steps and r_first["warmup"] >= args.steady_warmup:
                 return None   # the headline IS a steady-state measurement
             rs = run_single(None, None, None, mw, nw, steps=args.steady_steps, warmup=args.steady_warmup,
-                            st=r_first["st"], done=r_first["done"], power=True)
+                            st=r_first["st"], done=r_first["done"])
             return measured(rs, mw, nw, name, Aw, bw, cw, not args.no_parity)
 
         if want_steady:

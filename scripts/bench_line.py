@@ -21,4 +21,4 @@ for name, leg in (j.get("steady") or {}).items():
     rs = leg["roofline"]
     print(tag, "steady", name, round(leg["value"], 1), "pivots/s;", rs.get("kernel"), round((rs.get("avg_kernel_ms") or 0) * 1e3, 1),
           "us x", rs["launches_sampled"], "frac", None if rs["frac"] is None else round(rs["frac"], 3), "parity",
-          (leg.get("parity_after_timed_region") or {}).get("ok"), "power", leg.get("board_power"))
+          (leg.get("parity_after_timed_region") or {}).get("ok"))
