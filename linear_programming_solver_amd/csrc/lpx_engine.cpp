@@ -126,7 +126,18 @@ static void apply_layout_options(lpx_state* s) {
 
 int sync_ctl_to_host(lpx_state* s) {
   HIP_TRY(hipMemcpyAsync(s->h_ctl, s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
+  // a bounded wait inside a sweep kernel that ran out sets a device word: it travels with the loop state (no extra sync)
+  unsigned* const fw = lpxk::sweep_fail_word(s->R, s->B.ld);
+  unsigned* const h_fw = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(s->h_ctl) + sizeof(LpxCtl));
+  if (fw) HIP_TRY(hipMemcpyAsync(h_fw, fw, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
   HIP_TRY(hipStreamSynchronize(s->stream));
+  if (fw && *h_fw) {
+    const unsigned f = *h_fw;
+    *h_fw = 0;
+    (void)hipMemset(fw, 0, sizeof(unsigned));
+    return fail(LPX_DEVICE_ERROR, "k_sweep64_pull: a hand-over wait between the two stages hit its spin bound (code " +
+                                      std::to_string(f) + "); the tableau of this handle is not valid");
+  }
   return 0;
 }
 
@@ -238,9 +249,9 @@ int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t
   ALLOC(s->ring, 2, LpxCtl);
   ALLOC(s->prow2, ld, double);
 #undef ALLOC
-  hipError_t e = hipHostMalloc((void**)&s->h_ctl, sizeof(LpxCtl), hipHostMallocDefault);
+  hipError_t e = hipHostMalloc((void**)&s->h_ctl, sizeof(LpxCtl) + 16, hipHostMallocDefault);   // + the sweep's fail word
   if (e != hipSuccess) { free_state(s); return fail(LPX_DEVICE_ERROR, "hipHostMalloc failed"); }
-  memset(s->h_ctl, 0, sizeof(LpxCtl));
+  memset(s->h_ctl, 0, sizeof(LpxCtl) + 16);
   if (hipHostMalloc((void**)&s->h_snap, 2 * sizeof(LpxCtl), hipHostMallocDefault) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_batch[0], hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&s->ev_batch[1], hipEventDisableTiming) != hipSuccess) {

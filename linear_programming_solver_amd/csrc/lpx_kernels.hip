@@ -2575,7 +2575,8 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_pull(double* __restrict__ A,
                                                          const double* __restrict__ prow_ring,
                                                          const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
                                                          const double* __restrict__ col_packed,   // [batch][64][4]
-                                                         unsigned* __restrict__ tickets) {
+                                                         unsigned* __restrict__ tickets,
+                                                         unsigned* __restrict__ fail_word) {
   constexpr int K = 32, RB = kDmaRB, NS = kPullNS, NM = kPullNM, HS = kPairHS, TR = 8;
   constexpr int kOps1 = RB + 2;                      // stage 1 per iteration: RB row DMAs, 1 multiplier DMA, 1 atomic
   constexpr int kAhead1 = (NS - 1) * kOps1;          // younger than the atomic of iteration i - NS at iteration i's wait
@@ -2694,7 +2695,10 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_pull(double* __restrict__ A,
           unsigned spins = 0;
           while (lds_word_load(&words[0]) < i + 1) {   // batch i handed over?
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 26)) break;   // (never in a healthy run: keeps a bug from hanging the device)
+            if (++spins > (1u << 26)) {   // never in a healthy run: keeps a bug from hanging the device, and says so
+              if (lane == 0) atomicOr(fail_word, 1u);   // (the host turns it into LPX_DEVICE_ERROR at the end of the loop)
+              break;
+            }
           }
           if (full >= NS) dma_wait<kAhead2>(); else if (i >= NS) dma_wait<0>();
           bq[NS] = lds_word_load(&tring[(i + NS) % TR]);   // published by stage 1 in ITS iteration i: it is past that
@@ -2720,7 +2724,10 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_pull(double* __restrict__ A,
             unsigned spins = 0;
             while (lds_word_load(&words[1]) < i - HS + 1) {
               __builtin_amdgcn_s_sleep(1);
-              if (++spins > (1u << 26)) break;
+              if (++spins > (1u << 26)) {
+                if (lane == 0) atomicOr(fail_word, 2u);
+                break;
+              }
             }
           }
           char* const hs = hand + u * kDmaSlotBytes + lane * 16;
@@ -3226,6 +3233,10 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
 // of a budget) would pay that inside its own run, so every kernel of the blocked loop is launched once per device
 // when the first ring is built — one workgroup each, with arguments that make it return at once (no pending pivots,
 // no rows, no decisions) and touch nothing but the ring's own words.
+unsigned* sweep_fail_word(const BlockRing& R, int64_t ld) {   // the last slot of the ticket buffer (never a counter)
+  return R.tickets ? R.tickets + (ld / 128 + 3) * 32 : nullptr;
+}
+
 void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) {
   static std::atomic<unsigned> done{0};
   int dev = 0;
@@ -3260,7 +3271,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
     hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed);
     hipLaunchKernelGGL(k_pack_multipliers<64>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed);
 #define LPX_PRE_PULL64(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
+    hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, sweep_fail_word(R, ld));
     LPX_EACH_NT_OOP(LPX_PRE_PULL64)
 #undef LPX_PRE_PULL64
   }
@@ -3399,7 +3410,7 @@ static void launch_sweep64_pull(const Buffers& B, const BlockRing& R, int m_loca
   const dim3 grid(npairs * G), block(256);
 #define LPX_LAUNCH_PULL64(NT_, OOP_)                                                                              \
   hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                     nstrips_full, R.col_packed, R.tickets)
+                     nstrips_full, R.col_packed, R.tickets, sweep_fail_word(R, B.ld))
   if (A_src) { if (nt) LPX_LAUNCH_PULL64(true, true); else LPX_LAUNCH_PULL64(false, true); }
   else { if (nt) LPX_LAUNCH_PULL64(true, false); else LPX_LAUNCH_PULL64(false, false); }
 #undef LPX_LAUNCH_PULL64
