@@ -76,6 +76,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_A2_OFFSET", 512, 0, 1 << 20},     // LPX_OPT_A2_OFFSET
     {"LPX_SWEEP_FORM", 0, 0, 2},            // LPX_OPT_SWEEP_FORM
     {"LPX_MULTI_ONEHOP", 0, 0, 1},          // LPX_OPT_MULTI_ONEHOP
+    {"LPX_SWEEP_CUS", 0, 0, 256},           // LPX_OPT_SWEEP_CUS
 };
 
 static const int64_t* env_defaults() {
@@ -647,7 +648,7 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
     HIP_TRY(hipEventRecord(s->ev[s->ev_used], stream));
   }
   // CUs the sweep's stream may use: all but the decisions' reserved ones on the masked overlap stream
-  const int cus = (stream == s->ov_sweep && s->ov_masked) ? device_cus(s) - s->ov_chain_cus : device_cus(s);
+  const int cus = (stream == s->ov_sweep && s->ov_masked) ? s->ov_sweep_cus : device_cus(s);
   int kernel_used = 0;
   s->info.sweep_rows = lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, (int)s->opt[LPX_OPT_SWEEP_ROWS],
                                                 s->nontemporal, stream, A_src, b_src,
@@ -689,9 +690,13 @@ int ensure_overlap_streams(lpx_state* s) {
   const int ncu = prop.multiProcessorCount;
   const int per_xcd = ncu / 8;
   std::vector<uint32_t> m_sweep((ncu + 31) / 32, 0u), m_chain((ncu + 31) / 32, 0u);
+  // LPX_OPT_SWEEP_CUS (a multiple of 8; 0 = all that is left): the sweep's share per XCD.  Fewer CUs = less fp64 power
+  // beside the decisions, whose latency follows the shader clock the power cap leaves (EXPERIMENTS.md section 0).
+  int sweep_per_xcd = per_xcd - kChainCusPerXcd;
+  if (s->opt[LPX_OPT_SWEEP_CUS] > 0) sweep_per_xcd = std::max(1, std::min(sweep_per_xcd, (int)s->opt[LPX_OPT_SWEEP_CUS] / 8));
   for (int cu = 0; cu < ncu; cu++) {
     if (cu / 8 >= per_xcd - kChainCusPerXcd) m_chain[cu / 32] |= 1u << (cu % 32);
-    else m_sweep[cu / 32] |= 1u << (cu % 32);
+    else if (cu / 8 < sweep_per_xcd) m_sweep[cu / 32] |= 1u << (cu % 32);
   }
   bool masked = false;
   if (s->opt[LPX_OPT_OVERLAP_MASK] != 0 && ncu >= 64) {
@@ -711,6 +716,7 @@ int ensure_overlap_streams(lpx_state* s) {
   }
   s->ov_masked = masked;
   s->ov_chain_cus = masked ? 8 * kChainCusPerXcd : ncu;
+  s->ov_sweep_cus = masked ? 8 * sweep_per_xcd : ncu;
   for (int k = 0; k < 2; k++) {
     HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_chain[k], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_sweep[k], hipEventDisableTiming));

@@ -56,6 +56,7 @@ struct lpx_state {
   hipStream_t ov_chain = nullptr, ov_sweep = nullptr;
   bool ov_masked = false;           // the pair was created with CU masks (else: plain streams, chain at high priority)
   int ov_chain_cus = 0;             // CUs the chain stream may use
+  int ov_sweep_cus = 0;           // CUs of the sweep stream's mask (LPX_OPT_SWEEP_CUS)
   hipEvent_t ev_ov_chain[2] = {nullptr, nullptr}, ev_ov_sweep[2] = {nullptr, nullptr}, ev_ov_join[3] = {nullptr, nullptr, nullptr};
   double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
