@@ -551,8 +551,8 @@ static int build_block_ring(lpx_state* s) {
   HIP_TRY(hipMemsetAsync(const_cast<double*>(s->R.zeros), 0, 256, s->stream));
   // k_sweep32_pull: a ticket counter per 128-column sub-strip (128 bytes apart) and the block's multipliers packed by
   // batches of 4 rows (1 KiB each)
-  HIP_TRY(hipMalloc((void**)&s->R.tickets, (size_t)(s->B.ld / 128 + 4) * 128));
-  HIP_TRY(hipMemsetAsync(s->R.tickets, 0, (size_t)(s->B.ld / 128 + 4) * 128, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.tickets, (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128));
+  HIP_TRY(hipMemsetAsync(s->R.tickets, 0, (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128, s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.col_packed, (size_t)(mp / 4 + 1) * 2048));
   HIP_TRY(hipMemsetAsync(s->R.col_packed, 0, (size_t)(mp / 4 + 1) * 2048, s->stream));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));

@@ -143,6 +143,7 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
 void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s);
 // device word the pull sweep kernels set when one of their (bounded) LDS waits ran out: 0 in a healthy run
 unsigned* sweep_fail_word(const BlockRing& R, int64_t ld);
+int64_t sweep_ticket_slots(int64_t ld);   // 128-byte slots of BlockRing::tickets for a row pitch of ld doubles
 // hipOccupancyMaxActiveBlocksPerMultiprocessor for k_block_chain (256 threads, its static LDS); >= 1
 int chain_blocks_per_cu();
 // apply the valid leading pending pivots (at most K) in one pass

@@ -3233,8 +3233,11 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
 // of a budget) would pay that inside its own run, so every kernel of the blocked loop is launched once per device
 // when the first ring is built — one workgroup each, with arguments that make it return at once (no pending pivots,
 // no rows, no decisions) and touch nothing but the ring's own words.
-unsigned* sweep_fail_word(const BlockRing& R, int64_t ld) {   // the last slot of the ticket buffer (never a counter)
-  return R.tickets ? R.tickets + (ld / 128 + 3) * 32 : nullptr;
+// The ticket buffer: one 128-byte slot per 128-column sub-strip (at least the four the preparing launches pull from),
+// then spare slots; the LAST slot is never a counter — it is the word a pull kernel sets when a bounded wait ran out.
+int64_t sweep_ticket_slots(int64_t ld) { return std::max<int64_t>(ld / 128, 4) + 4; }
+unsigned* sweep_fail_word(const BlockRing& R, int64_t ld) {
+  return R.tickets ? R.tickets + (sweep_ticket_slots(ld) - 1) * 32 : nullptr;
 }
 
 void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) {
