@@ -1005,6 +1005,11 @@ extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivot
     if (status) *status = s->h_ctl->status;
     if (track_slot) *track_slot = s->h_ctl->track;
     if (s->h_ctl->status == LPX_DIVIDE_BY_ZERO) return fail(LPX_DIVIDE_BY_ZERO, "pivot element is zero");
+    if (s->h_ctl->status == LPX_DEVICE_ERROR)   // written by the decision kernel itself: never a result, always an error
+      return fail(LPX_DEVICE_ERROR, "decision kernel: a wait between its workgroups hit its spin bound (code " +
+                                        std::to_string(s->h_ctl->reserved) + ": 0 / 1 grid barrier or a candidate record, "
+                                        "4 hand-off; + 1000 x decision) — were all of its " + std::to_string(s->info.chain_wgs) +
+                                        " workgroups resident?  The tableau of this handle is not valid");
     return 0;
   }
   // seed: entering scan + strided column gather / partials for the first pivot
