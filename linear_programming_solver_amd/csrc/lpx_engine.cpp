@@ -77,6 +77,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_SWEEP_FORM", 0, 0, 2},            // LPX_OPT_SWEEP_FORM
     {"LPX_MULTI_ONEHOP", 0, 0, 1},          // LPX_OPT_MULTI_ONEHOP
     {"LPX_SWEEP_CUS", 0, 0, 256},           // LPX_OPT_SWEEP_CUS
+    {"LPX_CHAIN_CUS", 0, 0, 16},            // LPX_OPT_CHAIN_CUS
 };
 
 static const int64_t* env_defaults() {
@@ -682,7 +683,19 @@ lpxk::BlockRing ring_half(const lpx_state* s, int h) {
 #ifndef LPX_CHAIN_CUS_PER_XCD
 #define LPX_CHAIN_CUS_PER_XCD 4
 #endif
-static constexpr int kChainCusPerXcd = LPX_CHAIN_CUS_PER_XCD;
+// By size (LPX_OPT_CHAIN_CUS = 0).  One row / one column per thread is the fastest decision (every further pass of a
+// thread is a serial round trip): up to 8192 rows / columns that is 32 workgroups on LPX_CHAIN_CUS_PER_XCD = 4 CUs per
+// XCD; above, where the loop is bound by the decisions and the sweep has slack (tableaus up to 1.5 GiB: cfg3), 8 CUs
+// per XCD hold 64 workgroups — cfg3 45.6k -> 49.8k pivots/s, same box; at 2 GiB and above (cfg4) the sweep is the
+// bound and keeps its 224 CUs (8 CUs per XCD there: -4 %).  profiles/r03_decision_grid.txt.
+static int chain_cus_per_xcd(const lpx_state* s, int per_xcd) {
+  int k = LPX_CHAIN_CUS_PER_XCD;
+  const int64_t work = std::max<int64_t>(s->m, s->B.ld);
+  const double bytes = 8.0 * (double)s->m * (double)s->B.ld;
+  if (!s->multi_shard && work > 8192 && bytes <= 1.5 * 1073741824.0) k = 8;
+  if (s->opt[LPX_OPT_CHAIN_CUS] > 0) k = (int)s->opt[LPX_OPT_CHAIN_CUS];
+  return std::max(1, std::min(k, per_xcd - 1));
+}
 int ensure_overlap_streams(lpx_state* s) {
   if (s->ov_chain) return 0;
   hipDeviceProp_t prop;
@@ -692,6 +705,7 @@ int ensure_overlap_streams(lpx_state* s) {
   std::vector<uint32_t> m_sweep((ncu + 31) / 32, 0u), m_chain((ncu + 31) / 32, 0u);
   // LPX_OPT_SWEEP_CUS (a multiple of 8; 0 = all that is left): the sweep's share per XCD.  Fewer CUs = less fp64 power
   // beside the decisions, whose latency follows the shader clock the power cap leaves (EXPERIMENTS.md section 0).
+  const int kChainCusPerXcd = chain_cus_per_xcd(s, per_xcd);
   int sweep_per_xcd = per_xcd - kChainCusPerXcd;
   if (s->opt[LPX_OPT_SWEEP_CUS] > 0) sweep_per_xcd = std::max(1, std::min(sweep_per_xcd, (int)s->opt[LPX_OPT_SWEEP_CUS] / 8));
   for (int cu = 0; cu < ncu; cu++) {
@@ -748,7 +762,10 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
   // speed the decisions up (cfg4: 16 / 32 / 64 workgroups -> 14.1k / 15.0k / 14.0k pivots/s)
   const int64_t work = std::max<int64_t>(s->m, s->B.ld);
   // (+1: with the first-positive rule workgroup 0 serves slots 0..255 only, see k_block_chain)
-  int auto_wgs = (int)std::min<int64_t>(32, std::max<int64_t>(1, (work + 511) / 512));
+  // one row / one column per thread, as far as the reserved CUs go (two per thread, the round-2 choice, was measured
+  // 5-18 % slower from 64 MiB to 512 MiB once the candidates travelled as tagged granules)
+  const int chain_cap = s->ov_masked ? std::max(32, s->ov_chain_cus) : 32;
+  int auto_wgs = (int)std::min<int64_t>(chain_cap, std::max<int64_t>(1, (work + 255) / 256));
   if (s->pricing == 0 && auto_wgs >= 8) auto_wgs += 1;
   // never more workgroups than the chain stream's CUs can hold at once: they spin at grid barriers
   const int chain_wgs = clamp_chain_wgs(s, s->opt[LPX_OPT_CHAIN_WGS] > 0 ? (int)s->opt[LPX_OPT_CHAIN_WGS] : auto_wgs,
@@ -841,10 +858,10 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   int64_t decided = 0;  // decisions issued (each either pivots or reports the end)
   // one persistent launch per block (k_block_chain) instead of three launches per decision; LPX_CHAIN=0: off
   const bool fused = s->opt[LPX_OPT_CHAIN] != 0 && s->row0 == 0 && s->m == s->m_global;
-  // serial form on the handle's own stream: by size, two rows / columns per thread (a grid barrier costs ~1 us at
-  // 32 workgroups, ~4 us at 128), never more than the device holds at once
+  // serial form on the handle's own stream: one row / column per thread up to 64 workgroups (the exchange grows with
+  // the grid: cfg4 alone 20.3 us per decision at 64 workgroups, 20.6 at 128), never more than the device holds at once
   const int64_t work = std::max<int64_t>(s->m, s->B.ld);
-  const int auto_wgs = (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 511) / 512));
+  const int auto_wgs = (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 255) / 256));
   const int chain_wgs = fused ? clamp_chain_wgs(s, s->opt[LPX_OPT_CHAIN_WGS] > 0 ? (int)s->opt[LPX_OPT_CHAIN_WGS] : auto_wgs,
                                                 device_cus(s))
                               : 0;
