@@ -590,10 +590,11 @@ int choose_block(const lpx_state* s) {
   int K = (int)s->opt[LPX_OPT_BLOCK];
   if (K == 0) {
     const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
-    // measured (scripts/block_policy.py): 32 MiB 57k pivots/s two-launch vs 54k blocked; 64 MiB 33k vs 57k (K = 16);
-    // 512 MiB K = 16 39.7k vs K = 32 37.9k; 1 GiB K = 32 45.8k
-    if (sweep_us < 15.0) K = 1;        // cache-resident tableaux: the two-launch loop wins
-    else if (sweep_us < 250.0) K = 16;
+    // measured with the round-3 decision grid (scripts/block_policy.py, profiles/r03_block_policy.txt), pivots/s:
+    // 16 MiB two-launch 71.1k vs K = 16 69.7k; 20 MiB 66.2k vs 69.2k; 32 MiB 56.7k vs 70.0k;
+    // 256 MiB K = 16 67.2k vs K = 32 65.8k; 384-448 MiB equal; 512 MiB 59.6k vs 63.2k; 1 GiB K = 32 50.6k vs 32.8k
+    if (sweep_us < 6.3) K = 1;         // up to ~18 MiB: the two-launch loop wins
+    else if (sweep_us < 150.0) K = 16; // up to ~430 MiB
     else K = 32;
     // 64: the two-stage sweep moves half the bytes per pivot and takes 0.74x the time per pivot alone on the chip, but
     // 64-slot decisions cost twice as much each (their ring reads grow with K^2) and take bandwidth from the sweep
