@@ -1,7 +1,7 @@
 """Soak test of the blocked loop's default form (persistent decision kernel beside out-of-place sweeps): many random
 LPs solved to optimality in random budget pieces, every intermediate state compared bit for bit with the fp64
 oracle.  A stale read between workgroups of k_block_chain would show up here as a mismatch.
-    python scripts/soak_chain.py [seconds=120]"""
+    python scripts/soak_chain.py [seconds=120] [MxN,MxN,...] [stop an LP after this many pivots]"""
 import os
 import sys
 import time
@@ -23,6 +23,9 @@ def main():
     t_end = time.time() + budget_s
     rng = np.random.default_rng(20261003)
     shapes = [(300, 700), (700, 1100), (1100, 260), (64, 2100), (513, 515), (900, 900)]
+    if len(sys.argv) > 2:   # "MxN,MxN,...": e.g. mid-size shapes, where the by-size grids of the decision kernel apply
+        shapes = [tuple(int(x) for x in sh.split("x")) for sh in sys.argv[2].split(",")]
+    max_lp_pivots = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # stop an LP after about this many pivots (big shapes)
     n_lp = n_cmp = pivots_total = 0
     while time.time() < t_end:
         m, n = shapes[n_lp % len(shapes)]
@@ -36,10 +39,11 @@ def main():
             opts["chain_wgs"] = 33     # the decision kernel at full width also on these small shapes
         st = lps.LPState(A, b, c, block=block, options=opts)
         ref = oracle.State(A, b, c, kind=oracle.FP64)
+        lp_piv = 0
         while True:
             budget = int(rng.choice([-1, 1, block, 3 * block + 1, 257, 1000]))
             got = st.simplex_loop(max_pivots=budget)
-            want = ref.simplex_loop(max_pivots=budget)
+            want = ref.simplex_loop(max_pivots=budget, threads=8 if m * n > (1 << 21) else 1)
             assert (got[0], got[1]) == (want["status"], want["pivots"]), (n_lp, m, n, block, budget, got, want)
             gA, gb, gc, gv, gp = st.read()
             wA, wb, wc, wv, wp = ref.read()
@@ -52,6 +56,9 @@ def main():
                 print("MISMATCH lp %d shape %dx%d block %d budget %d" % (n_lp, m, n, block, budget))
                 sys.exit(1)
             if got[0] != 9:  # not PIVOT_LIMIT: finished
+                break
+            lp_piv += got[1]
+            if max_lp_pivots >= 0 and lp_piv >= max_lp_pivots:
                 break
         st.close()
         n_lp += 1
