@@ -83,6 +83,23 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
     return out
 
 
+def loop_bound(ms_per_step, pivots_per_launch, avg_kernel_ms, info=None):
+    """Which of the two concurrent halves of the blocked loop sets the pace: one sweep launch applies
+    `pivots_per_launch` pivots while the decisions of the next block are taken beside it, so a block costs
+    max(decisions, sweep).  "decisions" when the block takes 10 % longer than its sweep (the sweep kernel then idles
+    part of the time and its roofline fraction says nothing about the loop), else "sweep"."""
+    try:
+        if not (avg_kernel_ms > 0) or not (pivots_per_launch >= 2):
+            return None
+        block_ms = ms_per_step * pivots_per_launch
+        if info is not None and not info.get("overlapped", 1):   # a budget of one block: nothing runs side by side
+            return {"block_ms": block_ms, "sweep_ms": avg_kernel_ms, "bound": "serial: the decisions, then one sweep"}
+        return {"block_ms": block_ms, "sweep_ms": avg_kernel_ms,
+                "bound": "decisions" if block_ms > 1.1 * avg_kernel_ms else "sweep"}
+    except Exception:
+        return None
+
+
 def load_traffic(workload, world, block, kernel):
     """PMC-measured HBM bytes per launch (profiles/traffic_*.json, scripts/pmc_traffic.py) and where the figure comes
     from — only when that file was measured for this workload, GPU count, pivots per sweep AND kernel; otherwise
@@ -399,7 +416,8 @@ def main():
         o = {"workload": "%s: m=%d n=%d, %d pivots after %d warm-up" % (name, mw, nw, r["steps"], r["warmup"]),
              "value": r["steps"] / r["elapsed"], "unit": "pivots/s", "ms_per_step": 1e3 * r["elapsed"] / r["steps"],
              "steps": r["steps"], "warmup": r["warmup"], "pivots_per_sweep": r["block"],
-             "roofline": roofline_block(mw, nw, r["pivots_per_launch"], r["avg_ms"], kern, r["launches"], traffic, tsrc)}
+             "roofline": roofline_block(mw, nw, r["pivots_per_launch"], r["avg_ms"], kern, r["launches"], traffic, tsrc),
+             "loop_bound": loop_bound(1e3 * r["elapsed"] / r["steps"], r["pivots_per_launch"], r["avg_ms"], r.get("info"))}
         if with_parity:
             o["parity_after_timed_region"] = parity_after(r["st"], Aw, bw, cw, r["done"], mw, nw, host_cores(),
                                                           args.parity_max_pivots)
@@ -610,6 +628,7 @@ def main():
                                ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline)))},
             "roofline": roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel_label(block, info), launches,
                                        *load_traffic(args.workload, world, block, kernel_label(block, info))),
+            "loop_bound": loop_bound(1e3 * elapsed / K, pivots_per_launch, avg_ms, info),
             "objective_after_timed_region": objective,
             "host_gen_s": t_gen,
             "host_upload_s": t_up,   # hipMalloc + PCIe upload of this rank's tableau; outside the timed region

@@ -2395,9 +2395,14 @@ __device__ __forceinline__ int ticket_take(unsigned& tk) {   // behind a wait th
 template <int KP>
 __global__ __launch_bounds__(256) void k_pack_multipliers(const double* __restrict__ col_ring, int64_t mp,
                                                           const LpxCtl* __restrict__ ring, int kmax, int nbt,
-                                                          double* __restrict__ colT) {
+                                                          double* __restrict__ colT, unsigned* __restrict__ tickets,
+                                                          int nsub) {
   __shared__ int sh_np;
   const int np = ring_count(ring, KP, kmax, &sh_np);
+  // the sweep's ticket counters start at zero (one per sub-strip, 128 bytes apart): cleared here, in the launch in
+  // front of the sweep, instead of by a memset launch of their own
+  if (blockIdx.x == 0)
+    for (int u = threadIdx.x; u < nsub; u += 256) tickets[u * 32] = 0u;
   const int s = threadIdx.x % KP;
   const int64_t b = (int64_t)blockIdx.x * (256 / KP) + threadIdx.x / KP;
   if (b >= nbt) return;
@@ -2931,8 +2936,18 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
     __syncthreads();
     if (t < m_local) {
       double v = col0_ring[(int64_t)s * mp + t];
-      for (int r = 0; r < np; ++r)
-        v = apply_pivot(v, t, j, sh_l[r], sh_e[r], sh_p[r], col_ring[(int64_t)r * mp + t], sh_x[r]);
+      // the ring values of eight steps are requested together (they do not depend on the running value): np / 8
+      // round trips instead of np
+      for (int r0 = 0; r0 < np; r0 += 8) {
+        double cv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cv[q] = (r0 + q < np) ? col_ring[(int64_t)(r0 + q) * mp + t] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = r0 + q;
+          if (r < np) v = apply_pivot(v, t, j, sh_l[r], sh_e[r], sh_p[r], cv[q], sh_x[r]);
+        }
+      }
       A[(int64_t)t * ld + j] = v;
     }
   } else if (job == 1) {  // pivot row of pending pivot s (if it lives on this shard), all columns
@@ -2942,15 +2957,31 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
     __syncthreads();
     if (t < (int)ld) {
       double v = t < n ? row0_ring[(int64_t)s * ld + t] : 0.0;
-      for (int r = 0; r < np; ++r)
-        v = apply_pivot(v, i, t, sh_l[r], sh_e[r], sh_p[r], sh_x[r], prow_ring[(int64_t)r * ld + t]);
+      for (int r0 = 0; r0 < np; r0 += 8) {
+        double pv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pv[q] = (r0 + q < np) ? prow_ring[(int64_t)(r0 + q) * ld + t] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = r0 + q;
+          if (r < np) v = apply_pivot(v, i, t, sh_l[r], sh_e[r], sh_p[r], sh_x[r], pv[q]);
+        }
+      }
       A[(int64_t)i * ld + t] = v;
     }
   } else {  // b of every local row (LPState.java:164 / :146)
     if (t < m_local) {
       double bi = b_src[t];  // == b unless the sweep ran out of place
-      for (int r = 0; r < np; ++r)
-        bi = (t == sh_l[r]) ? sh_bl[r] : __dsub_rn(bi, __dmul_rn(col_ring[(int64_t)r * mp + t], sh_bl[r]));
+      for (int r0 = 0; r0 < np; r0 += 8) {
+        double cv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cv[q] = (r0 + q < np) ? col_ring[(int64_t)(r0 + q) * mp + t] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = r0 + q;
+          if (r < np) bi = (t == sh_l[r]) ? sh_bl[r] : __dsub_rn(bi, __dmul_rn(cv[q], sh_bl[r]));
+        }
+      }
       b[t] = bi;
     }
   }
@@ -3271,8 +3302,8 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 1, R.col_packed, R.tickets);
   if (R.tickets && R.col_packed) {   // m_local = 0: the first ticket already names nothing
     LPX_EACH_NT_OOP(LPX_PRE_PULL)
-    hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed);
-    hipLaunchKernelGGL(k_pack_multipliers<64>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed);
+    hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0);
+    hipLaunchKernelGGL(k_pack_multipliers<64>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0);
 #define LPX_PRE_PULL64(NT_, OOP_) \
     hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, sweep_fail_word(R, ld));
     LPX_EACH_NT_OOP(LPX_PRE_PULL64)
@@ -3389,8 +3420,8 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
   const int nstrips_full = (int)(B.ld / 512);
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, nstrips_full)));
-  (void)hipMemsetAsync(R.tickets, 0, (size_t)nstrips_full * 4 * 128, s);
-  hipLaunchKernelGGL(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed);
+  hipLaunchKernelGGL(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed,
+                     R.tickets, nstrips_full * 4);
   const dim3 grid(nstrips_full * G), block(256);
 #define LPX_LAUNCH_PULL(NT_, OOP_)                                                                                \
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
@@ -3408,8 +3439,8 @@ static void launch_sweep64_pull(const Buffers& B, const BlockRing& R, int m_loca
   const int npairs = nstrips_full * 2;
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, npairs)));
-  (void)hipMemsetAsync(R.tickets, 0, (size_t)nstrips_full * 4 * 128, s);
-  hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed);
+  hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed,
+                     R.tickets, nstrips_full * 4);
   const dim3 grid(npairs * G), block(256);
 #define LPX_LAUNCH_PULL64(NT_, OOP_)                                                                              \
   hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
