@@ -137,7 +137,7 @@ typedef enum lpx_option {
   LPX_OPT_SWEEP_FORM = 14,    /* blocks of 17..32: 0 = k_sweep32_pull (LDS-DMA staging, batches pulled in address order; default), 1 = k_sweep32_steady (register staging, runs of rows), 2 = k_sweep32_dma (LDS-DMA, runs) */
   LPX_OPT_MULTI_ONEHOP = 15,  /* lpx_multi: 1 = every shard ships its candidate's row with its candidate (one cross-device hop per decision instead of two); 0 (default) = candidates, then the winner's normalised row */
   LPX_OPT_SWEEP_CUS = 16,     /* overlapped loop: CUs of the sweep stream's mask (multiple of 8; 0 = all but the decisions'); set before the first loop */
-  LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (1..16; 0 = by size); set before the first loop */
+  LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16 — other values are rounded down to a multiple of 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first loop */
   LPX_OPT_COUNT = 18
 } lpx_option;
 int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value);

@@ -694,8 +694,11 @@ static int chain_cus_per_xcd(const lpx_state* s, int per_xcd) {
   const int64_t work = std::max<int64_t>(s->m, s->B.ld);
   const double bytes = 8.0 * (double)s->m * (double)s->B.ld;
   if (!s->multi_shard && work > 8192 && bytes <= 1.5 * 1073741824.0) k = 8;
-  if (s->opt[LPX_OPT_CHAIN_CUS] > 0) k = (int)s->opt[LPX_OPT_CHAIN_CUS];
-  return std::max(1, std::min(k, per_xcd - 1));
+  // Multiples of 4 only: workgroups are dealt round the four shader engines of an XCD, so the reserved CUs must be the
+  // same number on each of them — with 6 per XCD (2 + 2 + 1 + 1) the 48-workgroup grid was not resident (measured:
+  // bounded wait -> LPX_DEVICE_ERROR; likewise one extra CU on one XCD, profiles/r03_decision_passes.txt).
+  if (s->opt[LPX_OPT_CHAIN_CUS] > 0) k = std::max(4, (int)s->opt[LPX_OPT_CHAIN_CUS] / 4 * 4);
+  return std::max(1, std::min(k, (per_xcd - 1) / 4 * 4));
 }
 int ensure_overlap_streams(lpx_state* s) {
   if (s->ov_chain) return 0;

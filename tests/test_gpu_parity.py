@@ -867,7 +867,20 @@ def test_cfg3_timed_form_200_pivots_vs_fp64_oracle(lps, oracle):
     info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (70, 200))
     assert info["block"] == 32 and info["overlapped"] == 1
     assert info["chain_wgs"] <= info["chain_resident_max"]
+    if info["chain_stream_masked"]:   # by size: 8 CUs per XCD for the decisions, one column per thread (workgroup 0 + 63)
+        assert info["chain_resident_max"] == 64 and info["chain_wgs"] == 64, info
     print("cfg3 placement:", info)
+
+
+@pytest.mark.parametrize("cus,resident", [(4, 32), (6, 32), (8, 64), (12, 96)])
+def test_decision_cus_option_vs_fp64_oracle(lps, oracle, cus, resident):
+    """Option chain_cus: CUs per XCD of the decision stream (multiples of 4 only — 6 is taken as 4: an uneven share
+    of an XCD's shader engines left the grid partly non-resident), one row / column per thread within them, on a
+    4096 x 12288 tableau (48 + 1 workgroups wanted) through two full blocks and a tail against the fp64 oracle."""
+    info = _timed_form_vs_oracle(lps, oracle, 4096, 12288, (45,), options={"chain_cus": cus, "block": 16})
+    assert info["overlapped"] == 1 and info["chain_wgs"] <= info["chain_resident_max"]
+    if info["chain_stream_masked"]:
+        assert info["chain_resident_max"] == resident and info["chain_wgs"] == min(49, resident), info
 
 
 def test_cfg3_one_pass_form_30_pivots_vs_fp64_oracle(lps, oracle):
