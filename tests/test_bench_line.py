@@ -1,0 +1,29 @@
+"""The pure helpers behind bench.py's JSON line: the bounded roofline of one sweep launch and which half of the blocked
+loop sets the pace (no GPU, no library)."""
+import math
+
+import bench
+
+
+def test_roofline_block_is_bounded_and_names_the_binding_term():
+    # cfg4, one sweep of 32 pivots in 1.72 ms: the HBM term (16 m n / 8 TB/s = 1.074 ms) is the larger lower bound
+    r = bench.roofline_block(32768, 16384, 32, 1.72, "k_sweep32_pull", 16)
+    assert r["bound"] == "hbm" and 0.62 < r["frac"] < 0.63 and r["frac"] <= 1.0
+    assert math.isclose(r["algorithmic_bytes_per_launch"], 16.0 * 32768 * 16384)
+    assert math.isclose(r["pivot_equiv_frac"], 32 * r["hbm_frac"])   # SURVEY 8(d)'s per-pivot figure
+    # 64 pivots per launch: 2 m n K / 39.3 T op/s = 1.749 ms > 1.074 ms, the fp64 term binds
+    r64 = bench.roofline_block(32768, 16384, 64, 3.30, "k_sweep64_pull", 8)
+    assert r64["bound"] == "fp64_valu" and r64["frac"] <= 1.0 and r64["unit"] == "TFLOP/s"
+    # nothing sampled: no fraction is invented
+    assert bench.roofline_block(8192, 16384, 32, float("nan"), "k", 0)["frac"] is None
+
+
+def test_loop_bound_names_the_slower_half():
+    # cfg4 steady: a block of 32 pivots every 1.945 ms, its sweep 1.786 ms -> the sweep sets the pace
+    assert bench.loop_bound(1.945 / 32, 32, 1.786, {"overlapped": 1})["bound"] == "sweep"
+    # cfg3 steady: 0.665 ms per block, sweep 0.484 ms -> the decisions do
+    assert bench.loop_bound(0.665 / 32, 32, 0.484, {"overlapped": 1})["bound"] == "decisions"
+    # a budget of one block (the driver's 20 pivots): nothing runs side by side
+    assert bench.loop_bound(1.87 / 20, 20, 1.40, {"overlapped": 0})["bound"].startswith("serial")
+    # one pass per pivot has no second half
+    assert bench.loop_bound(1.36, 1, 1.36, None) is None

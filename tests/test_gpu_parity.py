@@ -952,6 +952,27 @@ def test_wide_decision_kernel_vs_oracle(lps, oracle, shape, fences, block):
     st.close()
 
 
+@pytest.mark.parametrize("shape,block,wgs", [((1024, 2048), 1, None), ((1280, 2048), 16, 9), ((2048, 4096), 16, 17),
+                                             ((4096, 8192), 16, 32), ((8192, 8192), 32, 32)])
+def test_block_and_decision_grid_by_size(lps, oracle, shape, block, wgs):
+    """The by-size choices of the default loop (profiles/r03_block_policy.txt, r03_decision_grid.txt): one pass per pivot
+    up to ~18 MiB, blocks of 16 up to ~430 MiB, 32 above; the decision kernel with one row / column per thread (+ the
+    workgroup of the hand-off window), within the 32 CUs of its masked stream.  150 pivots against the fp64 oracle."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=m + 7 * n)
+    st = lps.LPState(A, b, c)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    assert st.block() == block
+    status, pivots, _ = st.simplex_loop(max_pivots=150)
+    want = ref.simplex_loop(max_pivots=150, threads=16)
+    assert (status, pivots) == (want["status"], want["pivots"])
+    assert_state_bits_equal(st.read(), ref.read(), "%s by-size loop" % (shape,))
+    info = st.info()
+    if wgs is not None and info["chain_stream_masked"]:
+        assert info["chain_wgs"] == wgs and info["chain_wgs"] <= info["chain_resident_max"], info
+    st.close()
+
+
 def test_decision_kernel_residency_is_bounded(lps):
     """lpx_state_get_info: the decision kernel's grid never exceeds what the CUs of its stream hold at once (its
     workgroups spin at grid barriers), whatever is requested; the placement census names the XCDs it ran on."""
