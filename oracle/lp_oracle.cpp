@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY (see dec15.hpp / lp_oracle.hpp).  extern "C" surface of the CPU
 // restatement, loaded with ctypes by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
-// kind 0 = decimal-15 (reference BigDecimal semantics), kind 1 = IEEE fp64 (what the GPU computes).
+// kind 0 = decimal-15 (reference BigDecimal semantics), kind 1 = IEEE fp64 (what the GPU computes), kind 2 = IEEE
+// fp64 with fused multiply-add updates (what the GPU computes in its opt-in fused-arithmetic mode, LPX_OPT_FUSED).
 // Inputs arrive as doubles; the decimal instantiation recovers the <=15-digit decimal each double was
 // written from (%.17g then HALF_UP to 15 digits), so fixtures written with short decimals are exact.
 #include <chrono>
@@ -19,7 +20,15 @@ struct Handle {
   int kind;
   State<Dec> sd;
   State<double> sf;
+  State<F64Fused> sx;
 };
+
+// run `fn` on the state of the handle's kind
+template <class F> auto with_state(Handle* h, F&& fn) {
+  if (h->kind == 0) return fn(h->sd);
+  if (h->kind == 2) return fn(h->sx);
+  return fn(h->sf);
+}
 
 template <class T>
 void fill_state(State<T>& st, int m, int n, const double* A, const double* b, const double* c, double v,
@@ -149,8 +158,7 @@ void* orc_state_new(int kind, int m, int n, const double* A, const double* b, co
                     const int32_t* perm, int with_perm) {
   Handle* h = new Handle();
   h->kind = kind;
-  if (kind == 0) fill_state(h->sd, m, n, A, b, c, v, perm, with_perm);
-  else fill_state(h->sf, m, n, A, b, c, v, perm, with_perm);
+  with_state(h, [&](auto& st) { fill_state(st, m, n, A, b, c, v, perm, with_perm); return 0; });
   return h;
 }
 
@@ -161,18 +169,19 @@ void orc_state_set_pricing(void* p, int pricing) {
   Handle* h = (Handle*)p;
   h->sd.pricing = pricing;
   h->sf.pricing = pricing;
+  h->sx.pricing = pricing;
 }
 
 int orc_get_entering(void* p) {
   Handle* h = (Handle*)p;
-  return h->kind == 0 ? h->sd.get_entering() : h->sf.get_entering();
+  return with_state(h, [](auto& st) { return st.get_entering(); });
 }
 
 // returns leaving row, -1 none, -2 IllegalArgumentException
 int orc_get_leaving(void* p, int entering) {
   Handle* h = (Handle*)p;
   try {
-    return h->kind == 0 ? h->sd.get_leaving(entering) : h->sf.get_leaving(entering);
+    return with_state(h, [&](auto& st) { return st.get_leaving(entering); });
   } catch (const std::domain_error&) {
     return -3;
   }
@@ -181,11 +190,10 @@ int orc_get_leaving(void* p, int entering) {
 // threads == 1: pivotSequentially; threads > 1: pivotConcurrently's partitioning
 int orc_pivot(void* p, int entering, int leaving, int threads) {
   Handle* h = (Handle*)p;
-  int m = h->kind == 0 ? h->sd.m : h->sf.m, n = h->kind == 0 ? h->sd.n : h->sf.n;
+  const int m = with_state(h, [](auto& st) { return st.m; }), n = with_state(h, [](auto& st) { return st.n; });
   if (entering < 0 || entering >= n || leaving < 0 || leaving >= m) return LPX_BAD_ARGUMENT;
   try {
-    if (h->kind == 0) h->sd.pivot(entering, leaving, threads);
-    else h->sf.pivot(entering, leaving, threads);
+    with_state(h, [&](auto& st) { st.pivot(entering, leaving, threads); return 0; });
   } catch (const DivideByZero&) {
     return LPX_DIVIDE_BY_ZERO;
   } catch (const std::domain_error&) {
@@ -196,20 +204,18 @@ int orc_pivot(void* p, int entering, int leaving, int threads) {
 
 void orc_state_dims(void* p, int32_t* m, int32_t* n, int32_t* has_perm) {
   Handle* h = (Handle*)p;
-  if (h->kind == 0) { *m = h->sd.m; *n = h->sd.n; *has_perm = !h->sd.perm.empty(); }
-  else { *m = h->sf.m; *n = h->sf.n; *has_perm = !h->sf.perm.empty(); }
+  with_state(h, [&](auto& st) { *m = st.m; *n = st.n; *has_perm = !st.perm.empty(); return 0; });
 }
 
 void orc_state_read(void* p, double* A, double* b, double* c, double* v, int32_t* perm) {
   Handle* h = (Handle*)p;
-  if (h->kind == 0) read_state(h->sd, A, b, c, v, perm);
-  else read_state(h->sf, A, b, c, v, perm);
+  with_state(h, [&](auto& st) { read_state(st, A, b, c, v, perm); return 0; });
 }
 
 // canonical text of every entry; returns needed size (incl. NUL) if cap too small
 int64_t orc_state_dump(void* p, char* out, int64_t cap) {
   Handle* h = (Handle*)p;
-  std::string s = h->kind == 0 ? dump_state(h->sd) : dump_state(h->sf);
+  std::string s = with_state(h, [](auto& st) { return dump_state(st); });
   if ((int64_t)s.size() + 1 > cap) return (int64_t)s.size() + 1;
   memcpy(out, s.c_str(), s.size() + 1);
   return 0;
@@ -223,9 +229,9 @@ double orc_simplex_loop(void* p, int64_t max_pivots, int threads, int64_t* pivot
   std::vector<PivotRecord> tr;
   int64_t piv = 0;
   auto t0 = std::chrono::steady_clock::now();
-  int st;
-  if (h->kind == 0) st = simplex_loop(h->sd, 2, max_pivots, piv, (int*)nullptr, trace ? &tr : nullptr, threads, LPX_UNBOUNDED);
-  else st = simplex_loop(h->sf, 2, max_pivots, piv, (int*)nullptr, trace ? &tr : nullptr, threads, LPX_UNBOUNDED);
+  const int st = with_state(h, [&](auto& state) {
+    return simplex_loop(state, 2, max_pivots, piv, (int*)nullptr, trace ? &tr : nullptr, threads, LPX_UNBOUNDED);
+  });
   auto t1 = std::chrono::steady_clock::now();
   *pivots_done = piv;
   *status = st;
@@ -245,10 +251,12 @@ namespace {
 template <class T> State<T>& handle_state(Handle* h);
 template <> State<Dec>& handle_state<Dec>(Handle* h) { return h->sd; }
 template <> State<double>& handle_state<double>(Handle* h) { return h->sf; }
+template <> State<F64Fused>& handle_state<F64Fused>(Handle* h) { return h->sx; }
 
 template <class T> std::string objective_text(const T& v);
 template <> std::string objective_text<Dec>(const Dec& v) { return dec15::set_scale6(v); }
 template <> std::string objective_text<double>(const double& v) { return round6_double(v); }
+template <> std::string objective_text<F64Fused>(const F64Fused& v) { return round6_double(v.x); }
 
 template <class T>
 Handle* solve_impl(int kind, int m, int n, const double* A, const double* b, const double* c, int maximize,
@@ -312,6 +320,8 @@ void* orc_solve2(int kind, int m, int n, const double* A, const double* b, const
                  int32_t* trace_out, int64_t trace_cap, int pricing) {
   if (kind == 0)
     return solve_impl<Dec>(kind, m, n, A, b, c, maximize, restore_order, max_pivots, threads, res, trace_out, trace_cap, pricing);
+  if (kind == 2)
+    return solve_impl<F64Fused>(kind, m, n, A, b, c, maximize, restore_order, max_pivots, threads, res, trace_out, trace_cap, pricing);
   return solve_impl<double>(kind, m, n, A, b, c, maximize, restore_order, max_pivots, threads, res, trace_out, trace_cap, pricing);
 }
 
@@ -327,8 +337,7 @@ int orc_solve_aux_lp(void* p, int index_of_x0, int mib) {
   Handle* h = (Handle*)p;
   int64_t piv = 0;
   int x0 = -1;
-  int st = h->kind == 0 ? solve_aux_lp(h->sd, index_of_x0, mib, -1, piv, x0, nullptr, 1)
-                        : solve_aux_lp(h->sf, index_of_x0, mib, -1, piv, x0, nullptr, 1);
+  const int st = with_state(h, [&](auto& state) { return solve_aux_lp(state, index_of_x0, mib, -1, piv, x0, nullptr, 1); });
   return st == LPX_OPTIMAL ? x0 : -1000 - st;
 }
 
@@ -336,15 +345,14 @@ int orc_solve_aux_lp(void* p, int index_of_x0, int mib) {
 void* orc_convert_into_aux_lp(int kind, int m, int n, const double* A, const double* b) {
   Handle* h = new Handle();
   h->kind = kind;
-  if (kind == 0) {
-    std::vector<Dec> Av((size_t)m * n), bv(m);
-    for (size_t i = 0; i < Av.size(); i++) Av[i] = dec15::from_double(A[i]);
-    for (int i = 0; i < m; i++) bv[i] = dec15::from_double(b[i]);
-    convert_into_aux_lp(m, n, Av, bv, h->sd);
-  } else {
-    std::vector<double> Av(A, A + (size_t)m * n), bv(b, b + m);
-    convert_into_aux_lp(m, n, Av, bv, h->sf);
-  }
+  with_state(h, [&](auto& st) {
+    typedef typename std::decay<decltype(st)>::type::N N;
+    std::vector<typename N::T> Av((size_t)m * n), bv(m);
+    for (size_t i = 0; i < Av.size(); i++) Av[i] = N::from_double(A[i]);
+    for (int i = 0; i < m; i++) bv[i] = N::from_double(b[i]);
+    convert_into_aux_lp(m, n, Av, bv, st);
+    return 0;
+  });
   return h;
 }
 
@@ -355,15 +363,12 @@ void* orc_restore_initial_lp(void* p, const double* c0, int n, int x0, const int
   Handle* h = new Handle();
   h->kind = a->kind;
   std::vector<int32_t> ord(order, order + n);
-  int st;
-  if (a->kind == 0) {
-    std::vector<Dec> cv(n);
-    for (int i = 0; i < n; i++) cv[i] = dec15::from_double(c0[i]);
-    st = restore_initial_lp(a->sd, cv, n, x0, ord, h->sd);
-  } else {
-    std::vector<double> cv(c0, c0 + n);
-    st = restore_initial_lp(a->sf, cv, n, x0, ord, h->sf);
-  }
+  const int st = with_state(a, [&](auto& aux) {
+    typedef typename std::decay<decltype(aux)>::type::N N;
+    std::vector<typename N::T> cv(n);
+    for (int i = 0; i < n; i++) cv[i] = N::from_double(c0[i]);
+    return restore_initial_lp(aux, cv, n, x0, ord, handle_state<typename N::T>(h));
+  });
   *status = st;
   if (st != LPX_OPTIMAL) { delete h; return nullptr; }
   return h;

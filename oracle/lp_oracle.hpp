@@ -43,6 +43,9 @@ template <> struct Num<dec15::Dec> {
   static T sub(const T& a, const T& b) { return dec15::sub(a, b); }
   static T mul(const T& a, const T& b) { return dec15::mul(a, b); }
   static T div(const T& a, const T& b) { return dec15::div(a, b); }
+  // x - round15(c*r) / x + round15(a*b): the update forms of LPState.java:162,164,171,177 (two roundings each)
+  static T submul(const T& x, const T& c, const T& r) { return dec15::sub(x, dec15::mul(c, r)); }
+  static T addmul(const T& x, const T& a, const T& b) { return dec15::add(x, dec15::mul(a, b)); }
   static T neg(const T& a) { return dec15::neg(a); }
   static T abs(const T& a) { return dec15::abs(a); }
   static int cmp(const T& a, const T& b) { return dec15::cmp(a, b); }
@@ -69,6 +72,8 @@ template <> struct Num<double> {
   static T sub(T a, T b) { return a - b; }
   static T mul(T a, T b) { return a * b; }
   static T div(T a, T b) { return a / b; }
+  static T submul(T x, T c, T r) { return x - c * r; }   // two roundings (-ffp-contract=off)
+  static T addmul(T x, T a, T b) { return x + a * b; }
   static T neg(T a) { return -a; }
   static T abs(T a) { return std::fabs(a); }
   static int cmp(T a, T b) { return a < b ? -1 : (a > b ? 1 : 0); }
@@ -79,6 +84,42 @@ template <> struct Num<double> {
   static std::string str(T a) {
     char buf[40];
     snprintf(buf, sizeof buf, "%a", a);
+    return buf;
+  }
+};
+
+// IEEE fp64 with every update x - c*r (LPState.java:162, :164, :177) and x + a*b (:171; LPSolver.java:223, :227)
+// computed as ONE fused multiply-add: the checker of the GPU's opt-in fused-arithmetic mode (LPX_OPT_FUSED).  The
+// reference rounds the product and the difference to 15 DECIMAL digits each; one binary rounding is no further from
+// that than two are (and is the more accurate of the two), but the bits differ from the unfused instantiation, so
+// the mode gets an instantiation of its own.  Everything else (divisions, comparisons) is the fp64 instantiation's.
+struct F64Fused {
+  double x;
+  F64Fused() : x(0.0) {}
+  explicit F64Fused(double v) : x(v) {}
+};
+template <> struct Num<F64Fused> {
+  typedef F64Fused T;
+  static T from_double(double x) { return T(x); }
+  static double to_double(T a) { return a.x; }
+  static T zero() { return T(0.0); }
+  static T one() { return T(1.0); }
+  static T eps() { return T(1e-9); }
+  static T inf() { return T(1e50); }
+  static T add(T a, T b) { return T(a.x + b.x); }
+  static T sub(T a, T b) { return T(a.x - b.x); }
+  static T mul(T a, T b) { return T(a.x * b.x); }
+  static T div(T a, T b) { return T(a.x / b.x); }
+  static T submul(T x, T c, T r) { return T(std::fma(-c.x, r.x, x.x)); }   // one rounding: v_fma_f64 with a negated factor
+  static T addmul(T x, T a, T b) { return T(std::fma(a.x, b.x, x.x)); }
+  static T neg(T a) { return T(-a.x); }
+  static T abs(T a) { return T(std::fabs(a.x)); }
+  static int cmp(T a, T b) { return a.x < b.x ? -1 : (a.x > b.x ? 1 : 0); }
+  static bool is_zero(T a) { return a.x == 0.0; }
+  static constexpr bool kSkipZeroMultiplier = false;   // fma(-0, y, -0.0) keeps -0.0, but the GPU never skips either
+  static std::string str(T a) {
+    char buf[40];
+    snprintf(buf, sizeof buf, "%a", a.x);
     return buf;
   }
 };
@@ -148,9 +189,9 @@ template <class T> struct State {
       if (N::kSkipZeroMultiplier && N::is_zero(ce)) continue;
       for (int j = 0; j < n; j++) {
         if (j == entering) continue;
-        row[j] = N::sub(row[j], N::mul(ce, prow[j]));                             // :162
+        row[j] = N::submul(row[j], ce, prow[j]);                                  // :162
       }
-      b[i] = N::sub(b[i], N::mul(ce, b_entering));                                // :164
+      b[i] = N::submul(b[i], ce, b_entering);                                     // :164
     }
   }
 
@@ -181,12 +222,12 @@ template <class T> struct State {
       update_rows(0, m, entering, leaving, piv, b_entering);
     }
     const T pc = c[entering];                                                      // :170
-    v = N::add(v, N::mul(b[leaving], pc));                                        // :171
+    v = N::addmul(v, b[leaving], pc);                                             // :171
     c[entering] = N::neg(N::div(pc, piv));                                        // :172
 #pragma omp parallel for num_threads(threads) schedule(static) if (threads > 1)
     for (int i = 0; i < n; i++) {
       if (i == entering) continue;
-      c[i] = N::sub(c[i], N::mul(pc, prow[i]));                                   // :177
+      c[i] = N::submul(c[i], pc, prow[i]);                                        // :177
     }
     exchange_indexes(entering, leaving);                                           // :180
   }
@@ -322,10 +363,10 @@ int restore_initial_lp(const State<T>& aux, const std::vector<T>& c0, int n, int
     int cur = slot_of[index];                                                      // :220
     if (cur >= na) {                                                               // :221
       const int r = cur - na;
-      v = N::add(v, N::mul(aux.b[r], k));                                          // :223
+      v = N::addmul(v, aux.b[r], k);                                               // :223
       for (int j = 0; j < n; j++) {
         T coef = N::neg(st.a(r, j));                                               // :226
-        c[j] = N::add(c[j], N::mul(coef, k));                                      // :227
+        c[j] = N::addmul(c[j], coef, k);                                           // :227
       }
     } else {
       if (cur >= n) return LPX_RESTORE_INDEX_FAULT;  // ArrayIndexOutOfBoundsException at :231

@@ -16,6 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "liblporacle.so")
 
 DEC15 = 0  # decimal-15 HALF_UP: the reference's BigDecimal/MathContext(15, HALF_UP) semantics
 FP64 = 1   # IEEE double, unfused: what the HIP kernels compute
+FP64_FUSED = 2  # IEEE double with x - c*r as ONE fused multiply-add: the checker of the opt-in fused mode (LPX_OPT_FUSED)
 
 
 class OrcResult(C.Structure):

@@ -1,4 +1,4 @@
-"""Pins the oracle (oracle/lp_oracle.hpp, both the decimal-15 and the fp64 instantiation) against every
+"""Pins the oracle (oracle/lp_oracle.hpp: the decimal-15, the fp64 and the fused-fp64 instantiation) against every
 known-answer vector the reference's own tests hold for the hot path: LPStateSpec.groovy and
 LPSolverSpec.groovy, transcribed as data in tests/golden/reference_vectors.json.  All of these vectors are
 small integers / dyadic fractions, so the fp64 instantiation must reproduce them exactly too."""
@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 STATUS = {"OPTIMAL": 0, "UNBOUNDED": 1, "INFEASIBLE": 2}
-KINDS = [0, 1]  # DEC15, FP64
+KINDS = [0, 1, 2]  # DEC15, FP64, FP64_FUSED (every vector here is exact in all three)
 
 
 @pytest.mark.parametrize("kind", KINDS)
