@@ -21,8 +21,12 @@
  *       of row i.  Ids 0..n-1 are the caller's original variables, n..n+m-1 the slacks of rows 0..m-1
  *       (this replaces the reference's two HashMaps `variables` / `coefficients`, LPState.java:27-28,
  *       swapped by exchangeIndexes, :311-320).
- * Arithmetic is IEEE fp64, one rounding per reference operation, never fused: t = ce*row[j]; a - t
- * (the reference rounds the product and the difference separately, LPState.java:162).
+ * Arithmetic is IEEE fp64.  Default: one rounding per reference operation, never fused: t = ce*row[j]; a - t
+ * (the reference rounds the product and the difference separately, LPState.java:162) — bit-identical to a plain
+ * unfused fp64 restatement of the reference.  Opt-in (LPX_OPT_FUSED, lpx_solve_options.fused): every update
+ * a - ce*row[j] is ONE fused multiply-add — one binary rounding where the reference has two decimal ones; same
+ * tolerance class against the reference's BigDecimal results (objective, basis), different bits, half the fp64
+ * instructions in the row-update kernels.
  *
  * Threading: a handle is single-caller (the reference classes are not thread-safe either); different
  * handles may be driven from different host threads.  All device work of a handle is issued on one HIP
@@ -38,7 +42,7 @@
 extern "C" {
 #endif
 
-#define LPX_ABI_VERSION 3
+#define LPX_ABI_VERSION 4
 
 /* Status codes.  One per exception message of the reference; the host shim maps them back
  * to the exact exception class + message because the reference's tests assert on the text. */
@@ -138,7 +142,8 @@ typedef enum lpx_option {
   LPX_OPT_MULTI_ONEHOP = 15,  /* lpx_multi: 1 = every shard ships its candidate's row with its candidate (one cross-device hop per decision instead of two); 0 (default) = candidates, then the winner's normalised row */
   LPX_OPT_SWEEP_CUS = 16,     /* overlapped loop: CUs of the sweep stream's mask (multiple of 8; 0 = all but the decisions'); set before the first loop */
   LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16 — other values are rounded down to a multiple of 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first loop */
-  LPX_OPT_COUNT = 18
+  LPX_OPT_FUSED = 18,         /* arithmetic of the updates x - c*r (LPState.java:162, :164, :177) and v + b*c (:171): 0 (default) = product and difference rounded separately, as the reference rounds them; 1 = one fused multiply-add each.  Every kernel of the handle switches together; set it before the first pivot of a solve (the two modes give different bits, so a switch in mid-solve matches neither checker) */
+  LPX_OPT_COUNT = 19
 } lpx_option;
 int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value);
 int lpx_state_get_option(const lpx_state* s, int32_t key, int64_t* value);
@@ -300,6 +305,9 @@ typedef struct lpx_solve_options {
   int32_t restore_order_len;    /* entries of restore_order; < 0: n (every original variable has a name).  With a
                                  * non-NULL restore_order, 0 means NO variable is substituted (an empty keySet());
                                  * a NULL restore_order selects the default-name order over all n variables          */
+  int32_t fused;                /* LPX_OPT_FUSED for the handle(s) of this solve: 0 = two roundings per update (default),
+                                 * 1 = fused multiply-add updates                                                     */
+  int32_t reserved;
 } lpx_solve_options;
 
 /* BigDecimal LPSolver.solve(LPStandardForm stForm)                      LPSolver.java:78

@@ -16,7 +16,25 @@ PRICING = {"reference": 0, "first-positive": 0, "dantzig": 1, 0: 0, 1: 1}
 # lpx_option (include/lpx.h)
 OPTIONS = {"block": 0, "chain": 1, "overlap": 2, "overlap_serial": 3, "overlap_mask": 4, "chain_wgs": 5,
            "chain_fences": 6, "sweep_rows": 7, "nt": 8, "batch": 9, "chain_trace": 10, "update_u": 11,
-           "update_rows": 12, "a2_offset": 13, "sweep_form": 14, "multi_onehop": 15, "sweep_cus": 16, "chain_cus": 17}
+           "update_rows": 12, "a2_offset": 13, "sweep_form": 14, "multi_onehop": 15, "sweep_cus": 16, "chain_cus": 17,
+           "fused": 18}
+
+# Arithmetic of the handles the host classes create when the caller does not say (option "fused" / LPSolver(fused=...)):
+# False = the default of the library (product and difference of every update rounded separately, as the reference rounds
+# them), True = fused multiply-add updates (LPX_OPT_FUSED).  See set_default_arithmetic().
+DEFAULT_FUSED = False
+
+
+def set_default_arithmetic(mode):
+    """"plain" (default) or "fused": what LPState / LPMulti / LPSolver / HipShardEngine select for new handles unless told
+    otherwise.  Returns the previous mode."""
+    global DEFAULT_FUSED
+    if mode not in ("plain", "fused"):
+        raise ValueError('arithmetic mode is "plain" or "fused"')
+    prev = "fused" if DEFAULT_FUSED else "plain"
+    DEFAULT_FUSED = mode == "fused"
+    return prev
+
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
@@ -57,6 +75,8 @@ class SolveOptions(C.Structure):
         ("keep_state", C.POINTER(C.c_void_p)),
         ("pricing", C.c_int32),
         ("restore_order_len", C.c_int32),
+        ("fused", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

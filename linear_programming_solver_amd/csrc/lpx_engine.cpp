@@ -78,6 +78,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_MULTI_ONEHOP", 0, 0, 1},          // LPX_OPT_MULTI_ONEHOP
     {"LPX_SWEEP_CUS", 0, 0, 256},           // LPX_OPT_SWEEP_CUS
     {"LPX_CHAIN_CUS", 0, 0, 16},            // LPX_OPT_CHAIN_CUS
+    {"LPX_FUSED", 0, 0, 1},                 // LPX_OPT_FUSED
 };
 
 static const int64_t* env_defaults() {
@@ -228,6 +229,7 @@ int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t
   const int64_t mp = std::max<int64_t>(2, round_up(m_local, 2)) + 2;
   s->B.ld = ld;
   memcpy(s->opt, env_defaults(), sizeof s->opt);
+  s->B.fused = s->opt[LPX_OPT_FUSED] != 0;
   apply_layout_options(s);
 #define ALLOC(ptr, count, type)                                                            \
   do {                                                                                     \
@@ -959,6 +961,7 @@ extern "C" int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value) {
   if (key == LPX_OPT_UPDATE_U && value == 3) return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: UPDATE_U is 1, 2 or 4");
   if (key == LPX_OPT_A2_OFFSET && s->A2) return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: the second tableau exists already");
   s->opt[key] = value;
+  if (key == LPX_OPT_FUSED) s->B.fused = value != 0;   // which of the two compilations of the kernels the launches take
   if (key == LPX_OPT_UPDATE_U || key == LPX_OPT_UPDATE_ROWS || key == LPX_OPT_NT) apply_layout_options(s);
   return 0;
 }

@@ -54,34 +54,14 @@ struct Buffers {
   RatioRow* partial;  // ntiles
   int32_t* perm;      // n + m_global
   LpxCtl* ctl;
+  int fused;          // 0: lpxk::plain kernels (two roundings per update, the default); 1: lpxk::fused (LPX_OPT_FUSED)
 };
 
-// ---- launch wrappers (all asynchronous on `s`) -------------------------------------------------------------
-void launch_entering(const Buffers& B, int n, hipStream_t s);
-// opt-in Dantzig pricing: overrides ctl->e_next after a decision (seed: at the start of a loop)
-void launch_entering_dantzig(const Buffers& B, int n, bool seed, hipStream_t s);
-// forced_e >= 0: use it as e_next instead of ctl->e_next (step API)
-void launch_ratio_gather(const Buffers& B, int m_local, int row0, const Geometry& g, int forced_e, hipStream_t s);
-void launch_reduce_partials(const Buffers& B, const Geometry& g, hipStream_t s);
-// forced_l >= 0 (global row): pivot(forced_e, forced_l) of the step API, no ratio test
-void launch_select_pivot(const Buffers& B, int n, int m_global, const Geometry& g, int forced_e, int forced_l,
-                         hipStream_t s);
-// prow / up: the normalised pivot row and the parameter block of the pivot to apply (B.prow / B.ctl in the
-// two-launch loop, one ring slot in the look-ahead pipeline)
-// A_out/b_out == nullptr: update (B.A, B.b) in place; otherwise read (B.A, B.b), write (A_out, b_out)
-void launch_update(const Buffers& B, int m_local, int n, int row0, const Geometry& g, bool nontemporal,
-                   const double* prow, const LpxCtl* up, double* A_out, double* b_out, hipStream_t s);
-// shards
-void launch_propose(const Buffers& B, int n, int row0, int m_local, const Geometry& g, double* d_candidate,
-                    hipStream_t s);
-void launch_commit(const Buffers& B, int n, int m_global, const double* d_gathered, int nranks, double* prow,
-                   LpxCtl* up, int up_parity, hipStream_t s);
-// look-ahead: candidate of the NEXT pivot computed from the tableau BEFORE the pending update `pend`
-void launch_peek(const Buffers& B, int n, int m_local, int row0, const double* prow_t, const double* col_t,
-                 double* col_next, const LpxCtl* pend, double* d_candidate, hipStream_t s);
 // blocked pivoting: ring of pending pivots (see lpx_kernels.hip "blocked pivoting")
 constexpr int kBlockMax = 64;        // pivots per block / slots per ring half (single-device loop)
 constexpr int kShardBlockMax = 32;   // the step-wise shard interface and lpx_multi decide at most this many per block
+constexpr int kChainMaxWgs = 256;   // <= one workgroup per CU: the whole grid is resident
+constexpr int kMaxDevices = 8;      // row-block shards of one lpx_multi (the GPUs of one node)
 struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per block in flight
   double* prow;   // kBlockMax x ld : normalised pivot row of pending pivot s
   double* col;    // kBlockMax x mp : column e_s of the tableau just before pivot s
@@ -108,18 +88,6 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   double* mg_candrow;              // one-hop form: candidate rows [2][kMaxDevices][ld]
   unsigned long long* mg_arrive2;  // one-hop form: arrival words of the candidate rows [2][kMaxDevices][kChainMaxWgs]
 };
-constexpr int kChainMaxWgs = 256;   // <= one workgroup per CU: the whole grid is resident
-constexpr int kMaxDevices = 8;      // row-block shards of one lpx_multi (the GPUs of one node)
-// decision number `np` of a block (np pivots pending): candidate record like k_propose's
-void launch_block_peek(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int np, double* d_candidate,
-                       hipStream_t s);
-void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_global, const double* d_gathered, int nranks,
-                         int slot, hipStream_t s);
-// all nb decisions of a block in one persistent launch (single shard: row0 == 0, m == m_global); wgs <= 0: auto.
-// The rings hold 2*kBlockMax slots: `half` is the block's, `old_half` that of the previous block when its sweep has
-// not yet reached the tableau (B.A, B.b) this launch reads (n_old pivots; 0: none).  b_from_tableau: first launch
-// of a loop.  seq: launch counter (the two barrier counters alternate).  host_snap: device-visible pointer to a
-// pinned host LpxCtl that receives the loop state when the launch ends.
 // Row-block shards on several devices deciding together (lpx_multi): what a shard's launch needs to know about its
 // peers.  Pointers are peer-mapped device pointers, index = shard rank; [dev] is the shard's own memory.
 struct MgPeers {
@@ -133,37 +101,19 @@ struct MgPeers {
   double* candrow[kMaxDevices];            // candidate rows [2][kMaxDevices][ld] of every shard
   unsigned long long* arrive2[kMaxDevices];// their arrival words [2][kMaxDevices][kChainMaxWgs]
 };
-// fences: grid-barrier form (bit 0 release fence, bit 1 acquire fence); trace: record phase timestamps in R.chain_dbg.
-// mg != NULL: the launch of one shard of an lpx_multi (m = the shard's rows); every shard must use the same wgs.
-void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
-                        int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
-                        hipStream_t s, const MgPeers* mg = nullptr);
-// one trivial launch of every kernel of the blocked loop, once per device (the runtime prepares a kernel at its first
-// launch); needs the handle's buffers and its ring (with chain_bar) allocated
-void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s);
-// device word the pull sweep kernels set when one of their (bounded) LDS waits ran out: 0 in a healthy run
-unsigned* sweep_fail_word(const BlockRing& R, int64_t ld);
-int64_t sweep_ticket_slots(int64_t ld);   // 128-byte slots of BlockRing::tickets for a row pitch of ld doubles
-// hipOccupancyMaxActiveBlocksPerMultiprocessor for k_block_chain (256 threads, its static LDS); >= 1
-int chain_blocks_per_cu();
-// apply the valid leading pending pivots (at most K) in one pass
-// A_src / b_src != NULL: out of place — read the tableau and b there, write the updated ones to B.A / B.b
-// rows_per_wg: rows one workgroup walks down (multiple of 64; <= 0: by size and by `cus`, the CUs the stream may use,
-// 0 = the whole device); returns the value used.  after_sweep: recorded between the sweep and the fix-up.
-// form (blocks of 17..32 over the full strips): 0 = k_sweep32_pull (round 3: LDS-DMA staging, every wave pulls its
-// batches in address order), 1 = k_sweep32_steady (round 2: register staging, runs of rows), 2 = k_sweep32_dma (LDS-DMA
-// staging, runs of rows).  *kernel_used (may be NULL): the SweepKernel that took the bulk of the tableau.
+// which kernel swept the bulk of the tableau (lpx_state_info.sweep_kernel)
 enum SweepKernel { kSweepNone = 0, kSweepTiles = 1, kSweepMulti = 2, kSweepSteady = 3, kSweepPipe64 = 4, kSweepDma = 5, kSweepPull = 6, kSweepPull64 = 7 };
-const char* sweep_kernel_name(int code);
-int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
-                       bool nt, hipStream_t s, const double* A_src = nullptr, const double* b_src = nullptr,
-                       hipEvent_t after_sweep = nullptr, int cus = 0, int form = 0, int* kernel_used = nullptr);
-// phase 1 / restore helpers
-void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s);
-void launch_drop_column(double* A, int64_t ld, int m, int n_old, int col, hipStream_t s);
 struct RestoreEntry { int32_t is_basic; int32_t index; double k; };  // index = row r (basic) or post-drop slot
-void launch_restore_objective(const Buffers& B, int n, const RestoreEntry* d_entries, int n_entries, hipStream_t s);
-void launch_checksum(const Buffers& B, int m_local, int n, int row0, unsigned long long* d_out3, hipStream_t s);
-void launch_transpose(const double* dA, int64_t lda, double* dAt, int64_t ldat, int m, int n, hipStream_t s);
+
+// ---- launch wrappers --------------------------------------------------------------------------------------------
+// lpx_kernels.hip is compiled twice: plain (one rounding per reference operation) and fused (updates as one FMA).
+namespace plain {
+#include "lpx_launchers.inc"
+}  // namespace plain
+namespace fused {
+#include "lpx_launchers.inc"
+}  // namespace fused
+// what the host engine calls: plain:: or fused:: by Buffers::fused (lpx_dispatch.cpp)
+#include "lpx_launchers.inc"
 
 }  // namespace lpxk

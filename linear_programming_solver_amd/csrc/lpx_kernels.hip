@@ -12,9 +12,16 @@
 //                                 known — the thread that owns that column also emits the next pivot column
 //                                 and the per-tile partial of the next ratio test (:287-305) in the same pass.
 //
-// Arithmetic is IEEE fp64 with exactly one rounding per reference operation (the reference rounds the
-// product and the difference of :162 separately): this file is compiled with -ffp-contract=off and the
-// hot expressions use __dmul_rn/__dsub_rn/__dadd_rn/__ddiv_rn so that no FMA can be formed.
+// Arithmetic is IEEE fp64.  This file is compiled TWICE, into two namespaces, and a handle picks one (LPX_OPT_FUSED,
+// Buffers::fused; lpx_dispatch.cpp):
+//   lpxk::plain (LPX_FUSED = 0, the default)  exactly one rounding per reference operation — the reference rounds the
+//       product and the difference of :162 separately, so the update is __dmul_rn then __dsub_rn, never an FMA;
+//   lpxk::fused (LPX_FUSED = 1, opt-in)       every update x - c*r (:162, :164, :177) and x + a*b (:171; LPSolver.java
+//       :223, :227) is ONE v_fma_f64: half the fp64 instructions of the sweep (which is at its VALU instruction floor
+//       in the plain form, profiles/r03_pmc) and one binary rounding instead of two where the reference has two decimal
+//       ones.  Checked bit for bit against the oracle's Num<F64Fused> instantiation.
+// The two differ in submul() / addmul() below and nowhere else; -ffp-contract=off keeps the compiler from forming
+// (or splitting) anything on its own.
 #include "lpx_kernels.h"
 
 #include <atomic>
@@ -26,9 +33,34 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef LPX_FUSED
+#define LPX_FUSED 0
+#endif
+
 namespace lpxk {
+#if LPX_FUSED
+namespace fused {
+#else
+namespace plain {
+#endif
 
 typedef double d2 __attribute__((ext_vector_type(2)));  // one 16-byte global access per lane
+
+// x - c*r and x + a*b: the ONLY place where the two arithmetic modes differ
+__device__ __forceinline__ double submul(double x, double c, double r) {
+#if LPX_FUSED
+  return __fma_rn(-c, r, x);
+#else
+  return __dsub_rn(x, __dmul_rn(c, r));
+#endif
+}
+__device__ __forceinline__ double addmul(double x, double a, double b) {
+#if LPX_FUSED
+  return __fma_rn(a, b, x);
+#else
+  return __dadd_rn(x, __dmul_rn(a, b));
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------ helpers
 __device__ __forceinline__ RatioRow rr_none() { return RatioRow{kInf, INT_MAX, 0}; }
@@ -203,7 +235,7 @@ __device__ __forceinline__ void finish_pivot(const double* __restrict__ raw_row,
     } else {
       const double x = (j < n) ? raw_row[j] : 0.0;
       const double pr = __ddiv_rn(x, p);                                           // :144
-      const double cn = __dsub_rn(c[j], __dmul_rn(pc, pr));                        // :177
+      const double cn = submul(c[j], pc, pr);                        // :177
       prow[j] = pr;
       c[j] = cn;
       if (j < n && cn > kEps && first_pos == INT_MAX) first_pos = j;  // j ascends per thread
@@ -235,7 +267,7 @@ __device__ __forceinline__ void finish_pivot(const double* __restrict__ raw_row,
       const double ce_new = -__ddiv_rn(pc, p);                                     // :172
       c[e] = ce_new;
       if (e < n && ce_new > kEps) e_min = min(e_min, e);  // possible on forced / degenerate pivots only
-      ctl->v = __dadd_rn(v_old, __dmul_rn(bl, pc));                                // :171
+      ctl->v = addmul(v_old, bl, pc);                                // :171
       perm[e] = perm_l;                                                            // exchangeIndexes :311-320
       perm[n + l_global] = perm_e;
       if (track >= 0) {                                                            // LPSolver.java:151-155
@@ -399,8 +431,8 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ A, const do
     } else {
 #pragma unroll
       for (int k = 0; k < U; ++k) {
-        x0[k].x = __dsub_rn(x0[k].x, __dmul_rn(ce0, pr[k].x));                     // :162
-        x0[k].y = __dsub_rn(x0[k].y, __dmul_rn(ce0, pr[k].y));
+        x0[k].x = submul(x0[k].x, ce0, pr[k].x);                     // :162
+        x0[k].y = submul(x0[k].y, ce0, pr[k].y);
       }
       if (eslot >= 0) {                                                            // :157
         const double ne = -__ddiv_rn(ce0, p);
@@ -426,8 +458,8 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ A, const do
       } else {
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-          x1[k].x = __dsub_rn(x1[k].x, __dmul_rn(ce1, pr[k].x));
-          x1[k].y = __dsub_rn(x1[k].y, __dmul_rn(ce1, pr[k].y));
+          x1[k].x = submul(x1[k].x, ce1, pr[k].x);
+          x1[k].y = submul(x1[k].y, ce1, pr[k].y);
         }
         if (eslot >= 0) {
           const double ne = -__ddiv_rn(ce1, p);
@@ -453,7 +485,7 @@ __global__ __launch_bounds__(256) void k_update(double* __restrict__ A, const do
         const int i = r ? i1 : i0;
         if (r && !has1) break;
         const double ce = r ? ce1 : ce0;
-        const double bn = (i == l) ? bl : __dsub_rn(bsrc[i], __dmul_rn(ce, bl));
+        const double bn = (i == l) ? bl : submul(bsrc[i], ce, bl);
         b[i] = bn;
         if (en >= 0) {
           double a = 0.0;
@@ -585,8 +617,8 @@ __global__ __launch_bounds__(256) void k_peek(const double* __restrict__ A, int6
         a = pe;
         bn = bl;
       } else {
-        a = (en == e_t) ? -__ddiv_rn(ce, p) : __dsub_rn(a_old, __dmul_rn(ce, pe));
-        bn = __dsub_rn(b[i], __dmul_rn(ce, bl));
+        a = (en == e_t) ? -__ddiv_rn(ce, p) : submul(a_old, ce, pe);
+        bn = submul(b[i], ce, bl);
       }
     }
     col_next[i] = a;
@@ -631,7 +663,7 @@ __global__ __launch_bounds__(1024) void k_peek_pack(const double* __restrict__ A
     cand[2] = best.ratio;
     cand[3] = have ? (double)best.row : -1.0;
     double bn = 0.0;
-    if (have) bn = !pending ? b[lr] : (lr == l_t ? bl : __dsub_rn(b[lr], __dmul_rn(ce, bl)));
+    if (have) bn = !pending ? b[lr] : (lr == l_t ? bl : submul(b[lr], ce, bl));
     cand[4] = bn;
     cand[5] = cand[6] = cand[7] = 0.0;
   }
@@ -641,7 +673,7 @@ __global__ __launch_bounds__(1024) void k_peek_pack(const double* __restrict__ A
       double x = row[j];
       if (pending) {
         if (lr == l_t) x = prow_t[j];
-        else x = (j == e_t) ? -__ddiv_rn(ce, p) : __dsub_rn(x, __dmul_rn(ce, prow_t[j]));
+        else x = (j == e_t) ? -__ddiv_rn(ce, p) : submul(x, ce, prow_t[j]);
       }
       cand[8 + j] = x;
     }
@@ -702,8 +734,8 @@ __global__ __launch_bounds__(256) void k_peek_multi(const double* __restrict__ A
         a = sh_pe[s];
         bi = sh_bl[s];
       } else {
-        a = (en == sh_e[s]) ? -__ddiv_rn(cs, sh_p[s]) : __dsub_rn(a, __dmul_rn(cs, sh_pe[s]));
-        bi = __dsub_rn(bi, __dmul_rn(cs, sh_bl[s]));
+        a = (en == sh_e[s]) ? -__ddiv_rn(cs, sh_p[s]) : submul(a, cs, sh_pe[s]);
+        bi = submul(bi, cs, sh_bl[s]);
       }
     }
     col_out[i] = a;
@@ -750,7 +782,7 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
     double bn = 0.0;
     if (have) {
       bn = b[lr];
-      for (int s = 0; s < np; ++s) bn = (lr == sh_l[s]) ? sh_bl[s] : __dsub_rn(bn, __dmul_rn(sh_cs[s], sh_bl[s]));
+      for (int s = 0; s < np; ++s) bn = (lr == sh_l[s]) ? sh_bl[s] : submul(bn, sh_cs[s], sh_bl[s]);
     }
     cand[4] = bn;
     cand[5] = cand[6] = cand[7] = 0.0;
@@ -763,7 +795,7 @@ __global__ __launch_bounds__(256) void k_pack_multi(const double* __restrict__ A
       for (int s = 0; s < np; ++s) {
         const double pr = prow_ring[(int64_t)s * ld + j];
         if (lr == sh_l[s]) x = pr;
-        else x = (j == sh_e[s]) ? -__ddiv_rn(sh_cs[s], sh_p[s]) : __dsub_rn(x, __dmul_rn(sh_cs[s], pr));
+        else x = (j == sh_e[s]) ? -__ddiv_rn(sh_cs[s], sh_p[s]) : submul(x, sh_cs[s], pr);
       }
       cand[8 + j] = x;
     }
@@ -885,13 +917,13 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
 // (phase B).  `on` is wave-uniform: steps outside the live range leave the value alone.
 #define LPX_CHAIN_STEP_A(on, cs_r, pe_r, l_r)                                      \
   {                                                                                \
-    const double t_ = __dsub_rn(a, __dmul_rn((cs_r), (pe_r)));                     \
+    const double t_ = submul(a, (cs_r), (pe_r));                     \
     const double nv_ = (ig == (l_r)) ? (pe_r) : t_;                                \
     a = (on) ? nv_ : a;                                                            \
   }
 #define LPX_CHAIN_STEP_B(on, cs_r, prv_r, e_r, dv_r)                               \
   {                                                                                \
-    const double t_ = __dsub_rn(x, __dmul_rn((cs_r), (prv_r)));                    \
+    const double t_ = submul(x, (cs_r), (prv_r));                    \
     const double nv_ = (j == (e_r)) ? (dv_r) : t_;                                 \
     x = (on) ? nv_ : x;                                                            \
   }
@@ -1408,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         cn = -__ddiv_rn(pc, p);                                                    // :172
       } else {
         pr = local_row ? __ddiv_rn(x, p) : ld_sys(&P.prow[(int64_t)s * ld + j]);   // :144 (the owner's value)
-        cn = __dsub_rn(cj, __dmul_rn(pc, pr));                                     // :177
+        cn = submul(cj, pc, pr);                                     // :177
       }
       if constexpr (MG) {
         if (owner && !onehop) {  // broadcast: the value goes into every other device's replica of the ring
@@ -1464,7 +1496,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
       const double* src_b = use_b ? &b[i] : &P.own_b[i];
       const double bcur = *src_b;
       P.own_dvc[(int64_t)s * mp + i] = (row0 + i == l) ? inv_p : -__ddiv_rn(colv, p);    // :157 / :139
-      P.own_b[i] = (row0 + i == l) ? bl : __dsub_rn(bcur, __dmul_rn(colv, bl));          // :146 / :164
+      P.own_b[i] = (row0 + i == l) ? bl : submul(bcur, colv, bl);          // :146 / :164
     }
     {
       const RatioRow w2 = rr_block_min(cand, sh_rr);
@@ -1475,7 +1507,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
       }
     }
     if (lead) {
-      v = __dadd_rn(v, __dmul_rn(bl, pc));                                         // :171
+      v = addmul(v, bl, pc);                                         // :171
       const int32_t perm_e = P.perm[e], perm_l = P.perm[n + l];                    // exchangeIndexes :311-320
       P.perm[e] = perm_l;
       P.perm[n + l] = perm_e;
@@ -1609,10 +1641,10 @@ __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], cons
 #pragma unroll
         for (int r = 0; r < RB; r += 2) {
           const d2 c2 = cc[s % (D + 1)][r / 2];
-          x[r].x = __dsub_rn(x[r].x, __dmul_rn(c2.x, pr[s].x));                      // LPState.java:162
-          x[r].y = __dsub_rn(x[r].y, __dmul_rn(c2.x, pr[s].y));
-          x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(c2.y, pr[s].x));
-          x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(c2.y, pr[s].y));
+          x[r].x = submul(x[r].x, c2.x, pr[s].x);                      // LPState.java:162
+          x[r].y = submul(x[r].y, c2.x, pr[s].y);
+          x[r + 1].x = submul(x[r + 1].x, c2.y, pr[s].x);
+          x[r + 1].y = submul(x[r + 1].y, c2.y, pr[s].y);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1624,10 +1656,10 @@ __device__ __forceinline__ void sweep_apply(d2 (&x)[RB], const d2 (&pr)[K], cons
 #pragma unroll
         for (int r = 0; r < RB; r += 2) {
           const d2 c2 = *reinterpret_cast<const d2*>(&sh_col[s][(r0 + r) & (kSweepMaxRows - 1)]);  // LDS broadcast
-          x[r].x = __dsub_rn(x[r].x, __dmul_rn(c2.x, pr[s].x));
-          x[r].y = __dsub_rn(x[r].y, __dmul_rn(c2.x, pr[s].y));
-          x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(c2.y, pr[s].x));
-          x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(c2.y, pr[s].y));
+          x[r].x = submul(x[r].x, c2.x, pr[s].x);
+          x[r].y = submul(x[r].y, c2.x, pr[s].y);
+          x[r + 1].x = submul(x[r + 1].x, c2.y, pr[s].x);
+          x[r + 1].y = submul(x[r + 1].y, c2.y, pr[s].y);
         }
       }
     }
@@ -2192,10 +2224,10 @@ __device__ __forceinline__ void sweep_apply_lin(d2 (&x)[RB], const d2 (&pr)[K], 
 #pragma unroll
     for (int r = 0; r < RB; r += 2) {
       const d2 c2 = cc[s % (D + 1)][r / 2];
-      x[r].x = __dsub_rn(x[r].x, __dmul_rn(c2.x, pr[s].x));                      // LPState.java:162
-      x[r].y = __dsub_rn(x[r].y, __dmul_rn(c2.x, pr[s].y));
-      x[r + 1].x = __dsub_rn(x[r + 1].x, __dmul_rn(c2.y, pr[s].x));
-      x[r + 1].y = __dsub_rn(x[r + 1].y, __dmul_rn(c2.y, pr[s].y));
+      x[r].x = submul(x[r].x, c2.x, pr[s].x);                      // LPState.java:162
+      x[r].y = submul(x[r].y, c2.x, pr[s].y);
+      x[r + 1].x = submul(x[r + 1].x, c2.y, pr[s].x);
+      x[r + 1].y = submul(x[r + 1].y, c2.y, pr[s].y);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -2903,7 +2935,7 @@ __device__ __forceinline__ double apply_pivot(double v, int i, int j, int l_r, i
                                               double pr_j) {
   if (i == l_r) return pr_j;                       // pivot row := normalised row (pr_j = 1/p at j == e_r)
   if (j == e_r) return -__ddiv_rn(ce, p_r);        // :157
-  return __dsub_rn(v, __dmul_rn(ce, pr_j));        // :162
+  return submul(v, ce, pr_j);        // :162
 }
 
 // After the sweep: recompute the entering columns (job 0), the pivot rows (job 1) and b (job 2) of the valid
@@ -2979,7 +3011,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int r = r0 + q;
-          if (r < np) bi = (t == sh_l[r]) ? sh_bl[r] : __dsub_rn(bi, __dmul_rn(cv[q], sh_bl[r]));
+          if (r < np) bi = (t == sh_l[r]) ? sh_bl[r] : submul(bi, cv[q], sh_bl[r]);
         }
       }
       b[t] = bi;
@@ -3024,7 +3056,7 @@ __global__ __launch_bounds__(256) void k_restore_objective(const double* __restr
       const RestoreEntry en = ent[t];
       if (en.is_basic) {
         const double coef = -A[(int64_t)en.index * ld + j];                        // :226
-        acc = __dadd_rn(acc, __dmul_rn(coef, en.k));                               // :227
+        acc = addmul(acc, coef, en.k);                               // :227
       } else if (en.index == j) {
         acc = __dadd_rn(acc, en.k);                                                // :231
       }
@@ -3034,7 +3066,7 @@ __global__ __launch_bounds__(256) void k_restore_objective(const double* __restr
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double v = 0.0;
     for (int t = 0; t < n_ent; ++t)
-      if (ent[t].is_basic) v = __dadd_rn(v, __dmul_rn(b[ent[t].index], ent[t].k)); // :223
+      if (ent[t].is_basic) v = addmul(v, b[ent[t].index], ent[t].k); // :223
     ctl->v = v;
   }
 }
@@ -3305,7 +3337,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
     hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0);
     hipLaunchKernelGGL(k_pack_multipliers<64>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0);
 #define LPX_PRE_PULL64(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, sweep_fail_word(R, ld));
+    hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, (sweep_fail_word)(R, ld));
     LPX_EACH_NT_OOP(LPX_PRE_PULL64)
 #undef LPX_PRE_PULL64
   }
@@ -3444,7 +3476,7 @@ static void launch_sweep64_pull(const Buffers& B, const BlockRing& R, int m_loca
   const dim3 grid(npairs * G), block(256);
 #define LPX_LAUNCH_PULL64(NT_, OOP_)                                                                              \
   hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                     nstrips_full, R.col_packed, R.tickets, sweep_fail_word(R, B.ld))
+                     nstrips_full, R.col_packed, R.tickets, (sweep_fail_word)(R, B.ld))
   if (A_src) { if (nt) LPX_LAUNCH_PULL64(true, true); else LPX_LAUNCH_PULL64(false, true); }
   else { if (nt) LPX_LAUNCH_PULL64(true, false); else LPX_LAUNCH_PULL64(false, false); }
 #undef LPX_LAUNCH_PULL64
@@ -3659,4 +3691,5 @@ void launch_transpose(const double* dA, int64_t lda, double* dAt, int64_t ldat, 
   hipLaunchKernelGGL(k_transpose, dim3((n + 63) / 64, (m + 63) / 64), dim3(256), 0, s, dA, lda, dAt, ldat, m, n);
 }
 
+}  // namespace plain / fused
 }  // namespace lpxk

@@ -213,6 +213,9 @@ extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, con
   if (o.pricing != 0) {
     if (int rc = lpx_state_set_pricing(s, o.pricing)) { res->status = rc; return rc; }
   }
+  if (o.fused != 0) {
+    if (int rc = lpx_state_set_option(s, LPX_OPT_FUSED, 1)) { res->status = rc; return rc; }
+  }
   hipStream_t st = stream(s);
   lpxk::Buffers& B = buffers(s);
   double t_pivots = 0.0;
@@ -548,6 +551,9 @@ extern "C" int lpx_solve_multi(int32_t m, int32_t n, const double* A, int64_t ld
   guard.M = M;
   if (o.pricing != 0) {
     if (int rc = lpx_multi_set_pricing(M, o.pricing)) { res->status = rc; return rc; }
+  }
+  if (o.fused != 0) {
+    if (int rc = lpx_multi_set_option(M, LPX_OPT_FUSED, 1)) { res->status = rc; return rc; }
   }
   double t_pivots = 0.0;
   int status = LPX_OPTIMAL;

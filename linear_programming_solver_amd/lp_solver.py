@@ -31,10 +31,13 @@ class SolveInfo:
 
 
 class LPSolver:
-    def __init__(self, device=0, max_pivots=-1, pricing="reference", devices=None):
+    def __init__(self, device=0, max_pivots=-1, pricing="reference", devices=None, fused=None):
         """pricing="reference": the reference's first-positive rule (default, parity with the Java solver);
         pricing="dantzig": opt-in largest-coefficient rule (same optimum, ~10x fewer pivots, no pivot parity).
-        devices=[d0, d1, ...]: solve with the row blocks of the tableau on several GPUs (lpx_solve_multi)."""
+        devices=[d0, d1, ...]: solve with the row blocks of the tableau on several GPUs (lpx_solve_multi).
+        fused=True: every update x - c*r as one fused multiply-add (LPX_OPT_FUSED; one binary rounding where the
+        reference has two decimal ones, LPState.java:162 — checked against the oracle's fused instantiation)."""
+        self.fused = _lib.DEFAULT_FUSED if fused is None else bool(fused)
         self.device = int(device)
         self.devices = None if devices is None else [int(d) for d in devices]
         self.max_pivots = int(max_pivots)
@@ -54,6 +57,7 @@ class LPSolver:
         opts.has_variable_names = 1 if st_form.has_variable_names() else 0
         opts.max_pivots = self.max_pivots
         opts.pricing = self.pricing
+        opts.fused = 1 if self.fused else 0
         order = None
         if restore_order is not None:
             order = np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))
@@ -138,8 +142,9 @@ class LPSolver:
                 variables[st_form.n + i] = nm
                 coefficients[nm] = st_form.n + i
             return LPState(st_form.A, st_form.b, st_form.c, 0.0, variables, coefficients, st_form.m, st_form.n,
-                           device=self.device)
-        return LPState(st_form.A, st_form.b, st_form.c, 0.0, None, None, st_form.m, st_form.n, device=self.device)
+                           device=self.device, options={"fused": int(self.fused)})
+        return LPState(st_form.A, st_form.b, st_form.c, 0.0, None, None, st_form.m, st_form.n, device=self.device,
+                       options={"fused": int(self.fused)})
 
     def convert_into_aux_lp(self, st_form):
         """LPSolver.convertIntoAuxLP (LPSolver.java:283-321): extra column of -1, objective -x0, x0 named by
@@ -159,7 +164,8 @@ class LPSolver:
         for i, nm in enumerate(self.slack_names(coefficients, m)):
             variables[n + 1 + i] = nm
             coefficients[nm] = n + 1 + i
-        return LPState(auxA, st_form.b, auxc, 0.0, variables, coefficients, m, n + 1, device=self.device)
+        return LPState(auxA, st_form.b, auxc, 0.0, variables, coefficients, m, n + 1, device=self.device,
+                       options={"fused": int(self.fused)})
 
     def restore_initial_lp(self, aux_lp, initial, index_of_x0, restore_order=None):
         """LPSolver.restoreInitialLP (LPSolver.java:200-246), in place on the auxiliary LPState `aux_lp`, which

@@ -35,7 +35,7 @@ class HipShardEngine:
     current stream."""
 
     def __init__(self, A_local, b_local, c, row0, m_global, nranks, device=0, perm=None, v=0.0, stream=None,
-                 comm_stream=None, reserve_xcds=1, pricing="reference", pipeline=2):
+                 comm_stream=None, reserve_xcds=1, pricing="reference", pipeline=2, fused=None):
         import torch
         self.torch = torch
         L = _lib.lib()
@@ -58,6 +58,10 @@ class HipShardEngine:
         self._h = h
         if _lib.PRICING[pricing]:
             rc = L.lpx_state_set_pricing(h, _lib.PRICING[pricing])
+            if rc:
+                raise_for_status(rc)
+        if _lib.DEFAULT_FUSED if fused is None else fused:   # fused multiply-add updates (LPX_OPT_FUSED), every rank alike
+            rc = L.lpx_state_set_option(h, _lib.OPTIONS["fused"], 1)
             if rc:
                 raise_for_status(rc)
         dev = torch.device("cuda", self.device)

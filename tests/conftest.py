@@ -59,3 +59,35 @@ def oracle():
     pyoracle.build()
     pyoracle.lib()
     return pyoracle
+
+
+# ---- the two arithmetic modes of the HIP path ---------------------------------------------------------------------
+# Every GPU parity test runs twice: "plain" (the library's default: product and difference of every update rounded
+# separately, checked against the oracle's fp64 instantiation) and "fused" (LPX_OPT_FUSED: fused multiply-add updates,
+# checked against the oracle's fused instantiation).  The GPU test modules take their `lps` / `oracle` fixtures from the
+# two helpers below, so a test says `oracle.FP64` and gets the checker of the mode it runs in.
+@pytest.fixture(scope="session", params=["plain", "fused"])
+def arith(request):
+    return request.param
+
+
+class ArithOracle:
+    """oracle.pyoracle with FP64 standing for the binary instantiation of the current arithmetic mode."""
+
+    def __init__(self, mod, mode):
+        self._mod = mod
+        self.mode = mode
+        self.FP64 = mod.FP64_FUSED if mode == "fused" else mod.FP64
+
+    def __getattr__(self, name):
+        return getattr(self._mod, name)
+
+
+def package_in_mode(mode):
+    """The host package with new handles defaulting to `mode` (set_default_arithmetic)."""
+    import linear_programming_solver_amd as pkg
+    from linear_programming_solver_amd import _lib
+    _lib.lib()
+    assert _lib.lib().lpx_device_count() >= 1, "no HIP device visible"
+    pkg.set_default_arithmetic(mode)
+    return pkg

@@ -19,12 +19,22 @@ STATUS = {"OPTIMAL": 0, "UNBOUNDED": 1, "INFEASIBLE": 2}
 
 
 @pytest.fixture(scope="module")
-def lps():
-    import linear_programming_solver_amd as pkg
-    from linear_programming_solver_amd import _lib
-    _lib.lib()
-    assert _lib.lib().lpx_device_count() >= 1, "no HIP device visible"
-    return pkg
+def lps(arith):
+    """The host package; every test of this module runs in both arithmetic modes (tests/conftest.py `arith`)."""
+    from tests.conftest import package_in_mode
+    pkg = package_in_mode(arith)
+    yield pkg
+    pkg.set_default_arithmetic("plain")
+
+
+@pytest.fixture(scope="module")
+def oracle(arith):
+    """The checker of the current mode: oracle.FP64 is the fp64 instantiation ("plain") or the fused one ("fused")."""
+    from oracle import pyoracle
+    from tests.conftest import ArithOracle
+    pyoracle.build()
+    pyoracle.lib()
+    return ArithOracle(pyoracle, arith)
 
 
 def bits(a):
