@@ -209,6 +209,7 @@ def test_cfg5_phase1_through_four_shards_basis_bit_exact(lps):
     A, b, c = make_cfg5(m, n, gold["seed"])
     L = _lib.lib()
     opts = _lib.SolveOptions()
+    opts.fused = 1 if _lib.DEFAULT_FUSED else 0     # the raw C call: the arithmetic mode this test runs in
     opts.max_pivots = -1
     perm = np.zeros(n + m, dtype=np.int32)
     opts.perm_out = perm.ctypes.data_as(_lib.ip)

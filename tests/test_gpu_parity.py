@@ -186,6 +186,7 @@ def test_final_tableau_bits_after_solve(lps, oracle):
         want, wst = oracle.solve(A, b, c, True, kind=oracle.FP64)
         L = _lib.lib()
         opts = _lib.SolveOptions()
+        opts.fused = 1 if _lib.DEFAULT_FUSED else 0     # the raw C call: the arithmetic mode this test runs in
         opts.max_pivots = -1
         keep = C.c_void_p()
         opts.keep_state = C.pointer(keep)
@@ -452,6 +453,7 @@ def test_cfg5_degenerate_phase1_basis_bit_exact_vs_reference_semantics(lps, orac
     A, b, c = make_cfg5(m, n, gold["seed"])
     L = _lib.lib()
     opts = _lib.SolveOptions()
+    opts.fused = 1 if _lib.DEFAULT_FUSED else 0     # the raw C call: the arithmetic mode this test runs in
     opts.max_pivots = -1
     keep = C.c_void_p()
     opts.keep_state = C.pointer(keep)
@@ -616,6 +618,7 @@ def test_create_from_device_pointers(lps, oracle):
     rc = L.lpx_state_create_from_device(m, n, C.c_void_p(dA.data_ptr()), n, C.c_void_p(db.data_ptr()),
                                         C.c_void_p(dc.data_ptr()), 0.0, None, 0, m, 0, C.byref(h))
     assert rc == 0, _lib.last_error()
+    assert L.lpx_state_set_option(h, _lib.OPTIONS["fused"], 1 if _lib.DEFAULT_FUSED else 0) == 0
     piv, st = C.c_int64(), C.c_int32()
     assert L.lpx_simplex_loop(h, -1, C.byref(piv), C.byref(st), None) == 0
     ref = oracle.State(A, b, c, kind=oracle.FP64)
@@ -1014,6 +1017,7 @@ def test_solve_infeasible_with_exactly_sized_perm_out(lps):
     m, n = 2, 2
     guard = np.full(n + m + 8, 0x5A5A5A5A, dtype=np.int32)
     opts = _lib.SolveOptions()
+    opts.fused = 1 if _lib.DEFAULT_FUSED else 0     # the raw C call: the arithmetic mode this test runs in
     opts.max_pivots = -1
     opts.perm_out = guard.ctypes.data_as(_lib.ip)
     res = _lib.SolveResult()
