@@ -49,34 +49,48 @@ FP64_VALU_PEAK_TFLOPS = 39.3
 CHUNK = 1024
 
 
-def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traffic=None, traffic_source=None):
+def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traffic=None, traffic_source=None,
+                   fused=False, clock_mhz=0):
     """The bounded roofline figure of one row-update / sweep launch.
-    One launch reads and writes every fp64 entry once (16*m*n bytes — counter-verified, profiles/) and performs
-    2*m*n unfusable fp64 operations per pivot it applies.  Its time is bounded below by
-        t_hbm = 16*m*n / 8 TB/s        and        t_valu = 2*m*n*pivots_per_launch / 39.3 Tflop/s
-    frac = max(t_hbm, t_valu) / measured mean launch time (<= 1 by construction), `bound` names the larger term,
-    and achieved/peak are quoted in that bound's unit.  `pivot_equiv_frac` keeps SURVEY 8(d)'s per-PIVOT figure
-    (16*m*n bytes per pivot / 8 TB/s), which exceeds 1 when one sweep applies several pivots."""
+    One launch reads and writes every fp64 entry once (16*m*n bytes — counter-verified, profiles/) and issues, per entry
+    and pivot it applies, TWO fp64 instructions (v_mul_f64 + v_add_f64: the default arithmetic rounds the product and the
+    difference separately, LPState.java:162) or ONE (v_fma_f64, the opt-in fused mode).  Its time is bounded below by
+        t_hbm = 16*m*n / 8 TB/s     and     t_valu = instr*m*n*pivots_per_launch / (256 CUs x 4 SIMDs x 16 lanes x clock)
+    `frac` = max(t_hbm, t_valu at the NOMINAL 2.4 GHz = 39.3 T instr/s) / measured mean launch time: against the data-sheet
+    peaks, <= 1 by construction.  `bound` names the larger of t_hbm and t_valu AT THE CLOCK THE CHIP HELD during the sweep
+    (`clock_ghz`: in-kernel s_memtime against the 100 MHz counter, lpx_state_info.sweep_clock_mhz; nominal when it was not
+    measured): under the 1400 W package cap an fp64-dense sweep runs at 1.5-2.0 GHz and the instruction term is then the
+    larger one long before it is at 2.4 GHz.  `cycles_per_launch` = launch time x that clock (a kernel at its
+    instruction-issue floor costs the same cycles whatever the clock).  `pivot_equiv_frac` keeps SURVEY 8(d)'s per-PIVOT
+    figure (16*m*n bytes per pivot / 8 TB/s), which exceeds 1 when one sweep applies several pivots."""
     if not launches or not (avg_ms > 0):
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
                 "traffic_source": traffic_source, "kernel": kernel, "launches_sampled": launches}
     t = avg_ms * 1e-3
     bytes_moved = 16.0 * m_local * n
-    flops = 2.0 * m_local * n * pivots_per_launch
+    ipe = 1.0 if fused else 2.0                       # fp64 VALU instructions per entry and pivot
+    flops = ipe * m_local * n * pivots_per_launch     # lane-instructions
     t_hbm = bytes_moved / (HBM_PEAK_GBS * 1e9)
     t_valu = flops / (FP64_VALU_PEAK_TFLOPS * 1e12)
-    hbm_bound = t_hbm >= t_valu
-    out = {"bound": "hbm" if hbm_bound else "fp64_valu",
-           "achieved": bytes_moved / t / 1e9 if hbm_bound else flops / t / 1e12,
-           "peak": HBM_PEAK_GBS if hbm_bound else FP64_VALU_PEAK_TFLOPS,
-           "unit": "GB/s" if hbm_bound else "TFLOP/s",
+    clock_ghz = clock_mhz / 1e3 if clock_mhz and clock_mhz > 0 else None
+    t_valu_clk = flops / (256 * 4 * 16 * clock_ghz * 1e9) if clock_ghz else t_valu
+    hbm_peak_bound = t_hbm >= t_valu                  # which data-sheet peak `frac` / `achieved` are quoted against
+    out = {"bound": "hbm" if t_hbm >= t_valu_clk else "fp64_valu",
+           "bound_at": "measured clock" if clock_ghz else "nominal clock (not measured)",
+           "achieved": bytes_moved / t / 1e9 if hbm_peak_bound else flops / t / 1e12,
+           "peak": HBM_PEAK_GBS if hbm_peak_bound else FP64_VALU_PEAK_TFLOPS,
+           "unit": "GB/s" if hbm_peak_bound else "T fp64 instr/s",
            "frac": max(t_hbm, t_valu) / t,
            "traffic": traffic, "traffic_source": traffic_source,
            "kernel": kernel, "avg_kernel_ms": avg_ms, "launches_sampled": launches,
            "pivots_per_launch": pivots_per_launch,
-           "lower_bound_ms": {"hbm": 1e3 * t_hbm, "fp64_valu": 1e3 * t_valu},
+           "arithmetic": "fused (one v_fma_f64 per entry and pivot)" if fused else "two roundings (v_mul_f64 + v_add_f64 per entry and pivot)",
+           "clock_ghz": clock_ghz,
+           "cycles_per_launch": t * clock_ghz * 1e9 if clock_ghz else None,
+           "lower_bound_ms": {"hbm": 1e3 * t_hbm, "fp64_valu": 1e3 * t_valu, "fp64_valu_at_clock": 1e3 * t_valu_clk},
            "hbm_GBps": bytes_moved / t / 1e9, "hbm_frac": t_hbm / t,
-           "fp64_valu_TFLOPs": flops / t / 1e12, "fp64_valu_frac": t_valu / t,
+           "fp64_valu_Tinstr": flops / t / 1e12, "fp64_valu_frac": t_valu / t,
+           "fp64_valu_frac_at_clock": t_valu_clk / t,
            "algorithmic_bytes_per_launch": bytes_moved,
            "pivot_equiv_GBps": bytes_moved * pivots_per_launch / t / 1e9,
            "pivot_equiv_frac": bytes_moved * pivots_per_launch / t / 1e9 / HBM_PEAK_GBS}
@@ -124,16 +138,17 @@ def kernel_label(block, info, ld_is_whole_strips=True):
     return name
 
 
-def parity_after(st, A, b, c, pivots, m, n, threads, max_pivots):
-    """Replays `pivots` pivots of the same LP on the fp64 oracle (the checker, not the thing measured) and compares
-    what the timed handle holds now: v, perm, b, c bit for bit and the position-keyed checksum of the tableau."""
+def parity_after(st, A, b, c, pivots, m, n, threads, max_pivots, fused=False):
+    """Replays `pivots` pivots of the same LP on the fp64 oracle (the checker, not the thing measured; its fused
+    instantiation for a handle in the fused-arithmetic mode) and compares what the timed handle holds now: v, perm, b, c
+    bit for bit and the position-keyed checksum of the tableau."""
     if pivots > max_pivots:
         return {"checked": False, "reason": "%d pivots to replay > --parity-max-pivots %d" % (pivots, max_pivots)}
     from linear_programming_solver_amd.lp_state import checksum_host
     from oracle import pyoracle as orc
     orc.build()
     t0 = time.perf_counter()
-    ref = orc.State(A, b, c, kind=orc.FP64, with_perm=True)
+    ref = orc.State(A, b, c, kind=orc.FP64_FUSED if fused else orc.FP64, with_perm=True)
     r = ref.simplex_loop(max_pivots=pivots, threads=threads)
     wA, wb, wc, wv, wperm = ref.read()
     ref.close()
@@ -149,7 +164,8 @@ def parity_after(st, A, b, c, pivots, m, n, threads, max_pivots):
             "c": bool(np.array_equal(gc.view(np.uint64), wc.view(np.uint64))),
             "A_checksum": bool(st.checksum()[0] == sa)}
     return {"checked": True, "ok": all(same.values()) and r["pivots"] == pivots, "pivots_replayed": int(r["pivots"]),
-            "bit_identical": same, "oracle": "fp64 restatement, %d threads" % threads,
+            "bit_identical": same,
+            "oracle": "%s restatement, %d threads" % ("fp64 fused-multiply-add" if fused else "fp64", threads),
             "seconds": time.perf_counter() - t0}
 
 
@@ -270,6 +286,9 @@ def main():
     ap.add_argument("--no-steady", action="store_true",
                     help="N=1, cfg4: skip the `steady` object (the default loop for --steady-steps pivots after "
                          "--steady-warmup, cfg4 and cfg3, added when the headline run itself is shorter than that)")
+    ap.add_argument("--no-fused", action="store_true",
+                    help="N=1, cfg4: skip the `steady_fused` object (the steady-state protocol on fresh handles in the opt-in "
+                         "fused-arithmetic mode, cfg4 and cfg3, replayed on the oracle's fused instantiation)")
     ap.add_argument("--no-onepass", action="store_true",
                     help="skip the `onepass` object: the bandwidth-bound schedule north_star describes (one tableau pass "
                          "per pivot at N=1; two pivots per pass, the smallest block of the multi-GPU handle, at every N)")
@@ -373,14 +392,15 @@ def main():
         k, v = kv.split("=", 1)
         options[k] = int(v)
 
-    def run_single(Aw, bw, cw, mw, nw, steps=None, warmup=None, st=None, done=0):
+    def run_single(Aw, bw, cw, mw, nw, steps=None, warmup=None, st=None, done=0, opts=None):
         """warm-up + timed region of the single-GPU device loop on one workload; returns the measurements.
-        st: continue on this handle (it has done `done` pivots) instead of uploading the tableau again."""
+        st: continue on this handle (it has done `done` pivots) instead of uploading the tableau again.
+        opts: the handle's options (default: the --option set)."""
         Ks = K if steps is None else steps
         Ws = W if warmup is None else warmup
         t_up = time.perf_counter()
         if st is None:
-            st = LPState(Aw, bw, cw, device=local_rank, options=options)
+            st = LPState(Aw, bw, cw, device=local_rank, options=options if opts is None else opts)
         t_up = time.perf_counter() - t_up
         status, piv, _ = st.simplex_loop(max_pivots=Ws)
         assert piv == Ws, "LP finished during warm-up (status %d after %d pivots)" % (status, piv)
@@ -407,7 +427,7 @@ def main():
         avg_ms = kernel_ms / launches if launches else float("nan")
         return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms, "steps": Ks,
                 "warmup": Ws, "done": done + Ws + Ks, "pivots_per_launch": pivots_per_launch, "upload_s": t_up,
-                "info": st.info()}
+                "info": st.info(), "fused": bool(st.get_option("fused"))}
 
     def measured(r, mw, nw, name, Aw, bw, cw, with_parity):
         """one measurement as an object of the JSON line: value, roofline of its sweep / row-update launch, oracle replay"""
@@ -416,11 +436,12 @@ def main():
         o = {"workload": "%s: m=%d n=%d, %d pivots after %d warm-up" % (name, mw, nw, r["steps"], r["warmup"]),
              "value": r["steps"] / r["elapsed"], "unit": "pivots/s", "ms_per_step": 1e3 * r["elapsed"] / r["steps"],
              "steps": r["steps"], "warmup": r["warmup"], "pivots_per_sweep": r["block"],
-             "roofline": roofline_block(mw, nw, r["pivots_per_launch"], r["avg_ms"], kern, r["launches"], traffic, tsrc),
+             "roofline": roofline_block(mw, nw, r["pivots_per_launch"], r["avg_ms"], kern, r["launches"], traffic, tsrc,
+                                        fused=r.get("fused", False), clock_mhz=(r.get("info") or {}).get("sweep_clock_mhz", 0)),
              "loop_bound": loop_bound(1e3 * r["elapsed"] / r["steps"], r["pivots_per_launch"], r["avg_ms"], r.get("info"))}
         if with_parity:
             o["parity_after_timed_region"] = parity_after(r["st"], Aw, bw, cw, r["done"], mw, nw, host_cores(),
-                                                          args.parity_max_pivots)
+                                                          args.parity_max_pivots, fused=r.get("fused", False))
         return o
 
     def peer_selfcheck(devices):
@@ -475,44 +496,99 @@ def main():
                 err = "%s: %s" % (type(ex).__name__, ex)
         barrier()
         elapsed = time.perf_counter() - t0
-        onepass, extra_pivots = None, 0
+        onepass, onehop, grid_leg, ref_1gpu = None, None, None, None
+        counted = [0]               # pivots done behind the timed region, counted as they are done (the replay covers them)
+
+        def extra_loop(handle, budget):
+            piv = handle.simplex_loop(max_pivots=budget)[1]
+            if handle is mt:
+                counted[0] += int(piv)
+            return int(piv)
+
         if rank == 0 and err is None and not args.no_onepass:
             # the bandwidth-bound leg: blocks of 2 pivots (the smallest the multi-GPU handle runs), so that a scaling
             # record shows what row sharding multiplies (the sweep) next to the blocked number it barely changes
             try:
-                info_main = mt.info()
                 mt.set_option("block", 2)
-                mt.simplex_loop(max_pivots=16)
+                extra_loop(mt, 16)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                st2, piv2, _ = mt.simplex_loop(max_pivots=args.onepass_steps)
+                piv2 = extra_loop(mt, args.onepass_steps)
                 dt = time.perf_counter() - t1
-                extra_pivots = 16 + int(piv2)
                 onepass = {"pivots_per_pass": 2, "steps": int(piv2), "value": piv2 / dt, "unit": "pivots/s",
                            "ms_per_step": 1e3 * dt / max(1, piv2),
                            "what": "lpx_multi with blocks of 2 pivots: per pivot half a pass over every shard's rows "
                                    "(16*m*n/2 bytes in all) + one decision"}
-                mt.set_option("block", info_main["block"] if info_main["block"] > 2 else 0)
             except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
                 onepass = {"error": "%s: %s" % (type(ex).__name__, ex)}
-        onehop = None
+            finally:
+                mt.set_option("block", options.get("block", 0))
         if rank == 0 and err is None and nshards > 1 and not args.no_onepass:
             # the same blocked loop with the one-hop exchange (every shard ships its candidate's row with its candidate:
             # one cross-device hop per decision instead of two); bit-identical, so the replay below covers it as well
             try:
                 mt.set_option("multi_onehop", 1)
-                mt.simplex_loop(max_pivots=32)
+                extra_loop(mt, 32)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                _, piv3, _ = mt.simplex_loop(max_pivots=args.onehop_steps)
+                piv3 = extra_loop(mt, args.onehop_steps)
                 dt = time.perf_counter() - t1
-                extra_pivots += 32 + int(piv3)
                 onehop = {"steps": int(piv3), "value": piv3 / dt, "unit": "pivots/s", "ms_per_step": 1e3 * dt / max(1, piv3),
                           "used": int(mt.info().get("multi_onehop", 0)),
                           "what": "the blocked loop with LPX_OPT_MULTI_ONEHOP = 1 (opt-in; `value` is the default two-hop form)"}
-                mt.set_option("multi_onehop", 0)
             except Exception as ex:   # noqa: BLE001
                 onehop = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            finally:
+                mt.set_option("multi_onehop", options.get("multi_onehop", 0))
+        if rank == 0 and err is None and world > 1 and not args.no_onepass:
+            # third leg of the A/B (real devices only: with all shards on one GPU two 65-workgroup grids are not resident): one-hop exchange AND the by-size decision grid of the one-device loop (one row / one
+            # column per thread on 8 CUs per XCD), on a handle of its own (the CU share is fixed when a handle's streams
+            # are made); replayed on the oracle by itself
+            m2 = None
+            try:
+                m2 = LPMulti(Aw, bw, cw, devices=devices, options=dict(options, multi_onehop=1, chain_wgs=65, chain_cus=8))
+                extra_loop(m2, 64)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                piv4 = extra_loop(m2, args.onehop_steps)
+                dt = time.perf_counter() - t1
+                grid_leg = {"steps": int(piv4), "value": piv4 / dt, "unit": "pivots/s", "ms_per_step": 1e3 * dt / max(1, piv4),
+                            "engine": m2.info(),
+                            "what": "one-hop exchange + decision grid chain_wgs = 65 on chain_cus = 8 CUs per XCD (opt-in)"}
+                if not args.no_parity:
+                    grid_leg["parity_after_timed_region"] = parity_after(m2, Aw, bw, cw, 64 + int(piv4), m, n, host_cores(),
+                                                                         args.parity_max_pivots,
+                                                                         fused=bool(options.get("fused", 0)))
+            except Exception as ex:   # noqa: BLE001
+                grid_leg = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            finally:
+                if m2 is not None:
+                    m2.close()
+        if rank == 0 and err is None and world > 1 and not args.no_onepass:
+            # what the N-GPU numbers are speed-ups OF: the same job on GPU 0 alone, blocked (the default loop) and one
+            # pass per pivot (the schedule north_star's >= 6x was written against), measured in this very run
+            s1 = None
+            try:
+                s1 = LPState(Aw, bw, cw, device=devices[0], options=options)
+                s1.simplex_loop(max_pivots=W)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                p1 = s1.simplex_loop(max_pivots=K)[1]
+                dt1 = time.perf_counter() - t1
+                s1.set_option("block", 1)
+                s1.simplex_loop(max_pivots=8)
+                t1 = time.perf_counter()
+                p2 = s1.simplex_loop(max_pivots=max(8, args.onepass_steps // 2))[1]
+                dt2 = time.perf_counter() - t1
+                ref_1gpu = {"blocked": p1 / dt1, "one_pass_per_pivot": p2 / dt2, "unit": "pivots/s",
+                            "what": "the same tableau on GPU %d alone in this run: %d pivots after %d warm-up (default loop), "
+                                    "then %d pivots with one pass per pivot" % (devices[0], p1, W, p2)}
+            except Exception as ex:   # noqa: BLE001
+                ref_1gpu = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            finally:
+                if s1 is not None:
+                    s1.close()
+        extra_pivots = counted[0]
         barrier()
         if dist is not None:
             box = [err]
@@ -534,7 +610,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return {"st": mt, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms,
-                "pivots_per_launch": ppl, "upload_s": t_up, "info": info, "onepass": onepass, "onehop": onehop, "pivots_done": W + K + extra_pivots}
+                "pivots_per_launch": ppl, "upload_s": t_up, "info": info, "onepass": onepass, "onehop": onehop,
+                "grid_leg": grid_leg, "ref_1gpu": ref_1gpu, "pivots_done": W + K + extra_pivots}
 
     fallback_reason = None
     if peer:
@@ -627,7 +704,8 @@ def main():
                                world, ("blocked x%d" % block) if block > 1 else
                                ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline)))},
             "roofline": roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel_label(block, info), launches,
-                                       *load_traffic(args.workload, world, block, kernel_label(block, info))),
+                                       *load_traffic(args.workload, world, block, kernel_label(block, info)),
+                                       fused=bool(options.get("fused", 0)), clock_mhz=(info or {}).get("sweep_clock_mhz", 0)),
             "loop_bound": loop_bound(1e3 * elapsed / K, pivots_per_launch, avg_ms, info),
             "objective_after_timed_region": objective,
             "host_gen_s": t_gen,
@@ -642,41 +720,70 @@ def main():
             # the checker: the same LP replayed on the fp64 oracle for warm-up + steps pivots (outside the timed region)
             # (on the multi-GPU handle the bandwidth-bound leg has run behind the timed region: the replay covers it too)
             line["parity_after_timed_region"] = parity_after(st, A, b, c, r1_.get("pivots_done", W + K) if peer else W + K,
-                                                             m, n, host_cores(), args.parity_max_pivots)
+                                                             m, n, host_cores(), args.parity_max_pivots,
+                                                             fused=bool(options.get("fused", 0)))
         line["devices_visible"] = torch.cuda.device_count()
         if peer and r1_.get("onepass") is not None:
             line["onepass"] = r1_["onepass"]
         if peer and r1_.get("onehop") is not None:
             line["onehop"] = r1_["onehop"]
+        if peer and r1_.get("grid_leg") is not None:
+            line["onehop_grid"] = r1_["grid_leg"]
+        if peer and isinstance(r1_.get("ref_1gpu"), dict):
+            ref = r1_["ref_1gpu"]
+            line["ref_1gpu"] = ref
+            if "error" not in ref:
+                # side by side: north_star's >= 6x was written against the one-pass schedule
+                line["speedup_vs_blocked_1gpu"] = line["value"] / ref["blocked"]
+                if isinstance(r1_.get("onepass"), dict) and "error" not in r1_["onepass"]:
+                    line["speedup_onepass_vs_onepass_1gpu"] = r1_["onepass"]["value"] / ref["one_pass_per_pivot"]
+                line["speedup_vs_onepass_1gpu"] = line["value"] / ref["one_pass_per_pivot"]
         single = world == 1 and not sharded and not peer
         steady = {}
         want_steady = single and args.workload == "cfg4" and not args.no_steady
 
-        def steady_leg(r_first, Aw, bw, cw, mw, nw, name):
+        def steady_leg(r_first, Aw, bw, cw, mw, nw, name, with_parity):
             """The steady state of the default loop (>= 512 pivots after >= 64 warm-up), driver-run: the headline of a
             short command (the driver's 20 steps: one decision launch + one sweep, nothing overlapped, clocks still
             ramping) says little about the loop a solve spends its time in.  Continues on the same handle."""
             if r_first["steps"] >= args.steady_steps and r_first["warmup"] >= args.steady_warmup:
-                return None   # the headline IS a steady-state measurement
+                return None, r_first["done"]   # the headline IS a steady-state measurement
             rs = run_single(None, None, None, mw, nw, steps=args.steady_steps, warmup=args.steady_warmup,
                             st=r_first["st"], done=r_first["done"])
-            return measured(rs, mw, nw, name, Aw, bw, cw, not args.no_parity)
+            return measured(rs, mw, nw, name, Aw, bw, cw, with_parity), rs["done"]
 
+        def fused_leg(Aw, bw, cw, mw, nw, name):
+            """The same steady-state protocol on a FRESH handle in the opt-in fused-arithmetic mode (LPX_OPT_FUSED: every
+            update one v_fma_f64), replayed on the oracle's fused instantiation."""
+            rf = run_single(Aw, bw, cw, mw, nw, steps=args.steady_steps, warmup=args.steady_warmup,
+                            opts=dict(options, fused=1))
+            try:
+                return measured(rf, mw, nw, name, Aw, bw, cw, not args.no_parity)
+            finally:
+                rf["st"].close()
+
+        want_fused = want_steady and not args.no_fused and not options.get("fused", 0)
+        steady_fused = {}
+        done_total = W + K          # pivots the cfg4 handle has done (every leg below continues on it)
         if want_steady:
             r1_["done"] = W + K
-            leg = steady_leg(r1_, A, b, c, m, n, "cfg4")
+            # (its oracle replay comes after the one-pass legs, which continue on the same handle: one replay of everything)
+            leg, done_total = steady_leg(r1_, A, b, c, m, n, "cfg4", False)
             if leg is not None:
                 steady["cfg4"] = leg
         if single and not args.no_onepass:
             # the schedule north_star describes, on the same handle: one pass per pivot (k_update: the 16*m*n-bytes-per-
             # pivot roofline kernel), and two pivots per pass as the multi-GPU handle's bandwidth-bound leg runs them
+            counted = [done_total]
+
             def one_leg(block_opt, steps):
                 st.set_option("block", block_opt)
-                st.simplex_loop(max_pivots=8)
+                counted[0] += st.simplex_loop(max_pivots=8)[1]
                 st.profile_enable(1)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 _, piv2, _ = st.simplex_loop(max_pivots=steps)
+                counted[0] += piv2
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 ln, kms = st.profile_read()
@@ -685,31 +792,61 @@ def main():
                 return {"pivots_per_pass": block_opt, "steps": int(piv2), "value": piv2 / dt, "unit": "pivots/s",
                         "ms_per_step": 1e3 * dt / max(1, piv2),
                         "roofline": roofline_block(m, n, piv2 / float(ln) if ln else float("nan"),
-                                                   kms / ln if ln else float("nan"), kernel_label(block_opt, inf), ln)}
+                                                   kms / ln if ln else float("nan"), kernel_label(block_opt, inf), ln,
+                                                   fused=bool(options.get("fused", 0)))}
             try:
                 line["onepass"] = dict(one_leg(2, args.onepass_steps), one_pass_per_pivot=one_leg(1, args.onepass_steps // 2))
-                st.set_option("block", options.get("block", 0))
             except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
                 line["onepass"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            finally:
+                st.set_option("block", options.get("block", 0))
+                done_total = counted[0]
+        if single and not args.no_parity and done_total > W + K:
+            # ONE replay of everything the cfg4 handle has done: headline, steady leg, one-pass legs (k_update_tiles<2> and
+            # k_update at full height are checked here too)
+            final = parity_after(st, A, b, c, done_total, m, n, host_cores(), args.parity_max_pivots,
+                                 fused=bool(options.get("fused", 0)))
+            final["covers"] = "warm-up + steps, the steady leg and the one-pass legs: every pivot this handle has done"
+            if "cfg4" in steady:
+                steady["cfg4"]["parity_after_timed_region"] = final
+            if isinstance(line.get("onepass"), dict) and "error" not in line["onepass"]:
+                line["onepass"]["parity_after_timed_region"] = final
+        if single and args.workload == "cfg4" and (want_fused or not args.no_cfg3):
+            st.close()
+        if want_fused:
+            try:
+                steady_fused["cfg4"] = fused_leg(A, b, c, m, n, "cfg4")
+            except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
+                steady_fused["cfg4"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if single and args.workload == "cfg4" and not args.no_cfg3:
             # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
             # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)
-            st.close()
             m3, n3 = WORKLOADS["cfg3"]
             A3, b3, c3 = gen_rows(m3, n3, args.seed, 0, m3)
             r3 = run_single(A3, b3, c3, m3, n3)
             line["cfg3"] = measured(r3, m3, n3, "cfg3", A3, b3, c3, not args.no_parity)
             if want_steady:
-                leg = steady_leg(r3, A3, b3, c3, m3, n3, "cfg3")
+                leg, _ = steady_leg(r3, A3, b3, c3, m3, n3, "cfg3", not args.no_parity)
                 if leg is not None:
                     steady["cfg3"] = leg
             r3["st"].close()
+            if want_fused:
+                try:
+                    steady_fused["cfg3"] = fused_leg(A3, b3, c3, m3, n3, "cfg3")
+                except Exception as ex:   # noqa: BLE001
+                    steady_fused["cfg3"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
             del A3, b3, c3
         if steady:
             steady["protocol"] = ("the default loop continued on the same handle: %d more warm-up pivots, then %d timed "
                                   "pivots; roofline of its sweep launches; oracle replay of ALL pivots the handle has done"
                                   % (args.steady_warmup, args.steady_steps))
             line["steady"] = steady
+        if steady_fused:
+            steady_fused["protocol"] = ("a fresh handle with option fused = 1 (LPX_OPT_FUSED: every update x - c*r one "
+                                        "v_fma_f64; opt-in, `value` and `steady` are the default two-rounding arithmetic): "
+                                        "%d warm-up pivots, then %d timed pivots; replayed on the oracle's fused "
+                                        "instantiation" % (args.steady_warmup, args.steady_steps))
+            line["steady_fused"] = steady_fused
         if world == 1 and not peer and not args.no_cpu_baseline:
             rows_s = min(m, 8192)
             line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))

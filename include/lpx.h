@@ -164,7 +164,9 @@ typedef struct lpx_state_info {
   int32_t sweep_rows;           /* rows per workgroup (run length) of the last blocked sweep                       */
   int32_t sweep_kernel;         /* the kernel that swept the bulk of the tableau last (lpx_sweep_kernel_name)      */
   int32_t multi_onehop;         /* lpx_multi: 1 = the last decision launches used the one-hop exchange              */
-  int32_t reserved[3];
+  int32_t sweep_clock_mhz;      /* shader clock the chip held over the last k_sweep32_pull / k_sweep64_pull launch (in-kernel
+                                   s_memtime against the 100 MHz counter, probes in the launches around it); 0 = not measured */
+  int32_t reserved[2];
 } lpx_state_info;
 int lpx_state_get_info(lpx_state* s, lpx_state_info* out);
 /* Name of a lpx_state_info.sweep_kernel code as rocprofv3 prints it ("k_sweep32_dma", "k_update_tiles", ...; "" = none). */

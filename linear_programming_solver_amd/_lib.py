@@ -61,7 +61,7 @@ class StateInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "block", "chain_wgs", "chain_wgs_requested", "chain_resident_max", "chain_blocks_per_cu",
         "chain_stream_masked", "chain_xcd_mask", "sweep_xcd_mask", "overlapped", "nontemporal", "sweep_rows",
-        "sweep_kernel", "multi_onehop", "reserved0", "reserved1", "reserved2")]
+        "sweep_kernel", "multi_onehop", "sweep_clock_mhz", "reserved1", "reserved2")]
 
 
 class SolveOptions(C.Structure):

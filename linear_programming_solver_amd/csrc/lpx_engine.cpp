@@ -167,6 +167,7 @@ static void free_block_ring(lpx_state* s) {
   (void)hipFree(s->R.census);
   (void)hipFree(const_cast<double*>(s->R.zeros));
   (void)hipFree(s->R.tickets);
+  (void)hipFree(s->R.clk);
   (void)hipFree(s->R.col_packed);
   (void)hipFree(s->R.mg_mail);
   (void)hipFree(s->R.mg_arrive);
@@ -556,6 +557,8 @@ static int build_block_ring(lpx_state* s) {
   // batches of 4 rows (1 KiB each)
   HIP_TRY(hipMalloc((void**)&s->R.tickets, (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128));
   HIP_TRY(hipMemsetAsync(s->R.tickets, 0, (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.clk, 64));
+  HIP_TRY(hipMemsetAsync(s->R.clk, 0, 64, s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.col_packed, (size_t)(mp / 4 + 1) * 2048));
   HIP_TRY(hipMemsetAsync(s->R.col_packed, 0, (size_t)(mp / 4 + 1) * 2048, s->stream));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
@@ -987,6 +990,13 @@ extern "C" int lpx_state_get_info(lpx_state* s, lpx_state_info* out) {
     for (int w = 0; w < s->info.chain_wgs && w < (int)lpxk::kChainMaxWgs; w++)
       if (h[w]) s->info.chain_xcd_mask |= 1 << ((h[w] - 1) & 15);
     s->info.sweep_xcd_mask = (int32_t)h[lpxk::kChainMaxWgs];
+  }
+  s->info.sweep_clock_mhz = 0;
+  if (s->R.clk) {   // shader clock over the last pulled sweep: s_memtime ticks per 100 MHz tick between the two probes
+    long long c4[4] = {0, 0, 0, 0};
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(c4, s->R.clk, sizeof c4, hipMemcpyDeviceToHost));
+    if (c4[3] > c4[1] && c4[2] > c4[0]) s->info.sweep_clock_mhz = (int32_t)(100.0 * (double)(c4[2] - c4[0]) / (double)(c4[3] - c4[1]) + 0.5);
   }
   *out = s->info;
   return 0;

@@ -2428,9 +2428,12 @@ template <int KP>
 __global__ __launch_bounds__(256) void k_pack_multipliers(const double* __restrict__ col_ring, int64_t mp,
                                                           const LpxCtl* __restrict__ ring, int kmax, int nbt,
                                                           double* __restrict__ colT, unsigned* __restrict__ tickets,
-                                                          int nsub) {
+                                                          int nsub, long long* __restrict__ clk) {
   __shared__ int sh_np;
   const int np = ring_count(ring, KP, kmax, &sh_np);
+  // clock probe (lpx_state_info.sweep_clock_mhz): shader-clock and 100 MHz stamps in front of the sweep; k_block_fixup
+  // takes the matching pair behind it
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime(); clk[1] = wall_clock64(); }
   // the sweep's ticket counters start at zero (one per sub-strip, 128 bytes apart): cleared here, in the launch in
   // front of the sweep, instead of by a memset launch of their own
   if (blockIdx.x == 0)
@@ -2946,7 +2949,10 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
                                                      const double* __restrict__ col0_ring,
                                                      const double* __restrict__ row0_ring, int64_t mp,
                                                      const LpxCtl* __restrict__ ring, int kmax,
-                                                     const double* b_src) {
+                                                     const double* b_src, long long* __restrict__ clk) {
+  if (clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    clk[2] = __builtin_amdgcn_s_memtime(); clk[3] = wall_clock64();
+  }
   __shared__ double sh_p[kBlockMax], sh_bl[kBlockMax], sh_x[kBlockMax];
   __shared__ int sh_e[kBlockMax], sh_l[kBlockMax];
   __shared__ int sh_np;
@@ -3334,8 +3340,8 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 1, R.col_packed, R.tickets);
   if (R.tickets && R.col_packed) {   // m_local = 0: the first ticket already names nothing
     LPX_EACH_NT_OOP(LPX_PRE_PULL)
-    hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0);
-    hipLaunchKernelGGL(k_pack_multipliers<64>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0);
+    hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr);
+    hipLaunchKernelGGL(k_pack_multipliers<64>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr);
 #define LPX_PRE_PULL64(NT_, OOP_) \
     hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, (sweep_fail_word)(R, ld));
     LPX_EACH_NT_OOP(LPX_PRE_PULL64)
@@ -3354,7 +3360,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
 #undef LPX_PRE_TILES
 #undef LPX_EACH_NT_OOP
   hipLaunchKernelGGL(k_block_fixup, dim3(1, 1, 3), dim3(256), 0, s, A, ld, 0, 0, 0, B.b, R.prow, R.col, R.col0, R.row0,
-                     R.mp, R.up, 0, B.b);
+                     R.mp, R.up, 0, B.b, (long long*)nullptr);
   ChainArgs P{};   // nb = 0: every workgroup returns after reading the loop state (no barrier, nothing published)
   P.ctl = B.ctl; P.up = R.up; P.nb = 0;
   P.bar = R.chain_bar; P.bar_next = R.chain_bar + 32;
@@ -3453,7 +3459,7 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, nstrips_full)));
   hipLaunchKernelGGL(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed,
-                     R.tickets, nstrips_full * 4);
+                     R.tickets, nstrips_full * 4, R.clk);
   const dim3 grid(nstrips_full * G), block(256);
 #define LPX_LAUNCH_PULL(NT_, OOP_)                                                                                \
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
@@ -3472,7 +3478,7 @@ static void launch_sweep64_pull(const Buffers& B, const BlockRing& R, int m_loca
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, npairs)));
   hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed,
-                     R.tickets, nstrips_full * 4);
+                     R.tickets, nstrips_full * 4, R.clk);
   const dim3 grid(npairs * G), block(256);
 #define LPX_LAUNCH_PULL64(NT_, OOP_)                                                                              \
   hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
@@ -3662,7 +3668,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
   if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
-                     R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b);
+                     R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, R.clk);
   return rows_per_wg;
 }
 

@@ -56,6 +56,11 @@ def lib():
         return _lib
     if not os.path.exists(_LIB_PATH):
         build()
+    try:   # the library may have been built with -mfma on another machine (it travels with the repository snapshot)
+        if " fma " not in " " + open("/proc/cpuinfo").read().replace("\n", " ") + " ":
+            subprocess.check_call(["make", "-C", _HERE, "-B", "liblporacle.so", "FMA_FLAG="], stdout=subprocess.DEVNULL)
+    except OSError:
+        pass
     L = C.CDLL(_LIB_PATH)
     dp = C.POINTER(C.c_double)
     ip = C.POINTER(C.c_int32)

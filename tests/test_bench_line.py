@@ -13,7 +13,16 @@ def test_roofline_block_is_bounded_and_names_the_binding_term():
     assert math.isclose(r["pivot_equiv_frac"], 32 * r["hbm_frac"])   # SURVEY 8(d)'s per-pivot figure
     # 64 pivots per launch: 2 m n K / 39.3 T op/s = 1.749 ms > 1.074 ms, the fp64 term binds
     r64 = bench.roofline_block(32768, 16384, 64, 3.30, "k_sweep64_pull", 8)
-    assert r64["bound"] == "fp64_valu" and r64["frac"] <= 1.0 and r64["unit"] == "TFLOP/s"
+    assert r64["bound"] == "fp64_valu" and r64["frac"] <= 1.0 and r64["unit"] == "T fp64 instr/s"
+    # the same sweep of 32 at the clock an fp64-dense kernel really holds (1.56 GHz): the instruction term is the larger
+    # one there (2 m n K / (256 x 4 x 16 x 1.56 GHz) = 1.345 ms > 1.074 ms) although `frac` stays quoted against the
+    # data-sheet peaks; cycles per launch = time x clock
+    rc = bench.roofline_block(32768, 16384, 32, 1.80, "k_sweep32_pull", 16, clock_mhz=1560)
+    assert rc["bound"] == "fp64_valu" and rc["bound_at"] == "measured clock" and math.isclose(rc["frac"], r["frac"] * 1.72 / 1.80)
+    assert math.isclose(rc["cycles_per_launch"], 1.80e-3 * 1.56e9) and 1.34 < rc["lower_bound_ms"]["fp64_valu_at_clock"] < 1.35
+    # fused arithmetic: one instruction per entry and pivot, the memory pass binds again at that clock
+    rf = bench.roofline_block(32768, 16384, 32, 1.54, "k_sweep32_pull", 16, fused=True, clock_mhz=1900)
+    assert rf["bound"] == "hbm" and 0.69 < rf["frac"] < 0.70 and rf["arithmetic"].startswith("fused")
     # nothing sampled: no fraction is invented
     assert bench.roofline_block(8192, 16384, 32, float("nan"), "k", 0)["frac"] is None
 
