@@ -140,8 +140,8 @@ typedef enum lpx_option {
   LPX_OPT_A2_OFFSET = 13,     /* skew between the two tableau buffers in doubles (before the second one exists)      */
   LPX_OPT_SWEEP_FORM = 14,    /* blocks of 17..32: 0 = k_sweep32_pull (LDS-DMA staging, batches pulled in address order; default), 1 = k_sweep32_steady (register staging, runs of rows), 2 = k_sweep32_dma (LDS-DMA, runs) */
   LPX_OPT_MULTI_ONEHOP = 15,  /* lpx_multi: 1 = every shard ships its candidate's row with its candidate (one cross-device hop per decision instead of two); 0 (default) = candidates, then the winner's normalised row */
-  LPX_OPT_SWEEP_CUS = 16,     /* overlapped loop: CUs of the sweep stream's mask (multiple of 8; 0 = all but the decisions'); set before the first loop */
-  LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16 — other values are rounded down to a multiple of 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first loop */
+  LPX_OPT_SWEEP_CUS = 16,     /* overlapped loop: CUs of the sweep stream's mask (multiple of 8; 0 = all but the decisions'); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
+  LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16; other values are rounded down to a multiple of 4 but never below 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
   LPX_OPT_FUSED = 18,         /* arithmetic of the updates x - c*r (LPState.java:162, :164, :177) and v + b*c (:171): 0 (default) = product and difference rounded separately, as the reference rounds them; 1 = one fused multiply-add each.  Every kernel of the handle switches together; set it before the first pivot of a solve (the two modes give different bits, so a switch in mid-solve matches neither checker) */
   LPX_OPT_COUNT = 19
 } lpx_option;

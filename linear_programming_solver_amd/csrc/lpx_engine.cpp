@@ -963,6 +963,8 @@ extern "C" int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value) {
   if (value < sp.lo || value > sp.hi) return fail(LPX_BAD_ARGUMENT, std::string("lpx_state_set_option: value out of range for ") + sp.env);
   if (key == LPX_OPT_UPDATE_U && value == 3) return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: UPDATE_U is 1, 2 or 4");
   if (key == LPX_OPT_A2_OFFSET && s->A2) return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: the second tableau exists already");
+  if ((key == LPX_OPT_CHAIN_CUS || key == LPX_OPT_SWEEP_CUS) && s->ov_chain && value != s->opt[key])
+    return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: the CU-masked stream pair of this handle exists already (set CHAIN_CUS / SWEEP_CUS before the first blocked loop)");
   s->opt[key] = value;
   if (key == LPX_OPT_FUSED) s->B.fused = value != 0;   // which of the two compilations of the kernels the launches take
   if (key == LPX_OPT_UPDATE_U || key == LPX_OPT_UPDATE_ROWS || key == LPX_OPT_NT) apply_layout_options(s);

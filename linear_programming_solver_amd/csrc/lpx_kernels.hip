@@ -2407,11 +2407,13 @@ __device__ __forceinline__ void dma_piece1(const double* p, uint32_t lds) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(p), "s"(lds) : "memory");
 }
-// one returning atomic add by lane 0 (EXEC is all ones at every call site)
+// one returning atomic add by lane 0; EXEC is saved and restored inside the statement, so the call sites need not run
+// with all lanes enabled (they do today: wave-uniform branches only)
 __device__ __forceinline__ void ticket_pull(unsigned& tk, unsigned* ctr) {
   const unsigned zero = 0, one = 1;
-  asm volatile("s_mov_b64 exec, 1\n\ts_nop 0\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, -1"
-               : "=v"(tk) : "v"(zero), "v"(one), "s"(ctr) : "memory");
+  unsigned long long keep;
+  asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\ts_nop 0\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+               : "=v"(tk), "=&s"(keep) : "v"(zero), "v"(one), "s"(ctr) : "memory");
 }
 __device__ __forceinline__ int ticket_take(unsigned& tk) {   // behind a wait that covers the atomic
   __builtin_amdgcn_sched_barrier(0);
@@ -3590,7 +3592,8 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     // m not a multiple of 4) takes two passes of the generic kernel: slots 0..31 (out of place when asked), then
     // slots 32.. in place on the result.  An entry's update reads ring values only, so the split changes nothing.
     const int nstrips_full = (int)(B.ld / 512);
-    const bool geom = m_local % 4 == 0 && nstrips_full >= 1;
+    // (the pull kernels address a batch's rows by 32-bit byte offsets: 3 * ld * 8 + 1 KiB must stay below 2^32)
+    const bool geom = m_local % 4 == 0 && nstrips_full >= 1 && 3 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
     const bool pull = geom && form != 1 && R.tickets && R.col_packed;   // round 3: blocks of 33..64 valid pivots
     const bool pipe = geom && !pull && K == 64;                         // round 2: full blocks of 64 only
     int rows64 = 0;
@@ -3644,7 +3647,8 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
         rows48 = choose_pipe_rows(m_local, (int)(B.ld / 512), 2 * cus, 48);
         while (rows48 > 4 && (int64_t)rows48 * B.ld * 8 >= (int64_t)1 << 32) rows48 -= 4;   // 32-bit offsets
       }
-      if (form == 1 || !R.zeros || !R.tickets || !R.col_packed) {   // round 2: batches parked in registers, runs of rows
+      const bool wide32 = 3 * B.ld * 8 + 1024 >= ((int64_t)1 << 32);   // 32-bit row offsets of the LDS-DMA kernels would wrap
+      if (form == 1 || wide32 || !R.zeros || !R.tickets || !R.col_packed) {   // round 2: batches parked in registers, runs of rows
         launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
         used = kSweepSteady;
       } else if (form == 2) {   // LDS-DMA staging, runs of rows (diagnostics: the step between the two)

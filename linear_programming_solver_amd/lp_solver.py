@@ -179,8 +179,11 @@ class LPSolver:
             order = np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))
         elif initial.has_variable_names() and n > 0:
             order = self._key_set_order(initial)
+        # an EMPTY key set substitutes nothing (LPSolver.java:217 iterates zero names): a non-NULL pointer with length 0,
+        # as solve() passes it — NULL would select the default-name order over all n variables
+        keep = None if order is None else (order if order.size else np.zeros(1, dtype=np.int32))
         rc = L.lpx_restore_initial_lp(aux_lp._h, c0.ctypes.data_as(_lib.dp), n, int(index_of_x0),
-                                      None if order is None or not order.size else order.ctypes.data_as(_lib.ip),
+                                      None if keep is None else keep.ctypes.data_as(_lib.ip),
                                       0 if order is None else int(order.size))
         if rc:
             raise_for_status(rc)
