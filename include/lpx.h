@@ -143,7 +143,8 @@ typedef enum lpx_option {
   LPX_OPT_SWEEP_CUS = 16,     /* overlapped loop: CUs of the sweep stream's mask (multiple of 8; 0 = all but the decisions'); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
   LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16; other values are rounded down to a multiple of 4 but never below 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
   LPX_OPT_FUSED = 18,         /* arithmetic of the updates x - c*r (LPState.java:162, :164, :177) and v + b*c (:171): 0 (default) = product and difference rounded separately, as the reference rounds them; 1 = one fused multiply-add each.  Every kernel of the handle switches together; set it before the first pivot of a solve (the two modes give different bits, so a switch in mid-solve matches neither checker) */
-  LPX_OPT_COUNT = 19
+  LPX_OPT_CHAIN_FORM = 19,    /* decision kernel of the one-device blocked loop: 0 = k_block_chain_t (round 2/3), 1 = k_block_chain2_t (round 4: a phase asks for everything at once, nothing is drained on the critical path, workgroups of 512) */
+  LPX_OPT_COUNT = 20
 } lpx_option;
 int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value);
 int lpx_state_get_option(const lpx_state* s, int32_t key, int64_t* value);

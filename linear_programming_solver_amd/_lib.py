@@ -17,7 +17,7 @@ PRICING = {"reference": 0, "first-positive": 0, "dantzig": 1, 0: 0, 1: 1}
 OPTIONS = {"block": 0, "chain": 1, "overlap": 2, "overlap_serial": 3, "overlap_mask": 4, "chain_wgs": 5,
            "chain_fences": 6, "sweep_rows": 7, "nt": 8, "batch": 9, "chain_trace": 10, "update_u": 11,
            "update_rows": 12, "a2_offset": 13, "sweep_form": 14, "multi_onehop": 15, "sweep_cus": 16, "chain_cus": 17,
-           "fused": 18}
+           "fused": 18, "chain_form": 19}
 
 # Arithmetic of the handles the host classes create when the caller does not say (option "fused" / LPSolver(fused=...)):
 # False = the default of the library (product and difference of every update rounded separately, as the reference rounds

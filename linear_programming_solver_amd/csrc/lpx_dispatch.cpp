@@ -48,10 +48,10 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
                          int slot, hipStream_t s) {
   LPX_PICK(B, launch_block_decide)(B, R, n, m_global, d_gathered, nranks, slot, s);
 }
-void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
-                        int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
-                        hipStream_t s, const MgPeers* mg) {
-  LPX_PICK(B, launch_block_chain)(B, R, n, m, nb, half, old_half, n_old, b_from_tableau, seq, dantzig, wgs, fences, trace,
+int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
+                       int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
+                       hipStream_t s, const MgPeers* mg) {
+  return LPX_PICK(B, launch_block_chain)(B, R, n, m, nb, half, old_half, n_old, b_from_tableau, seq, dantzig, wgs, fences, trace,
                                   host_snap, s, mg);
 }
 // both sets: the arithmetic mode is an option of the handle and may be set after its ring has been built

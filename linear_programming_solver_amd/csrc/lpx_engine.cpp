@@ -79,6 +79,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_SWEEP_CUS", 0, 0, 256},           // LPX_OPT_SWEEP_CUS
     {"LPX_CHAIN_CUS", 0, 0, 16},            // LPX_OPT_CHAIN_CUS
     {"LPX_FUSED", 0, 0, 1},                 // LPX_OPT_FUSED
+    {"LPX_CHAIN_FORM", 0, 0, 1},            // LPX_OPT_CHAIN_FORM
 };
 
 static const int64_t* env_defaults() {
@@ -231,6 +232,7 @@ int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t
   s->B.ld = ld;
   memcpy(s->opt, env_defaults(), sizeof s->opt);
   s->B.fused = s->opt[LPX_OPT_FUSED] != 0;
+  s->B.chain_form = (int)s->opt[LPX_OPT_CHAIN_FORM];
   apply_layout_options(s);
 #define ALLOC(ptr, count, type)                                                            \
   do {                                                                                     \
@@ -797,14 +799,15 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
       if (k >= 1) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h ^ 1], 0));  // sweep k-1
       Brd.A = Abuf[h];
       Brd.b = bbuf[h];
-      lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, 0, 1, s->chain_seq++, s->pricing == 1, chain_wgs,
-                               fences, trace, d_snap + h, s->ov_chain);
+      s->info.chain_wgs = lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, 0, 1, s->chain_seq++, s->pricing == 1,
+                                                   chain_wgs, fences, trace, d_snap + h, s->ov_chain);
     } else {
       if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h], 0));  // sweep k-2
       Brd.A = Abuf[k == 0 ? 0 : (k - 1) & 1];
       Brd.b = bbuf[k == 0 ? 0 : (k - 1) & 1];
-      lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0, s->chain_seq++,
-                               s->pricing == 1, chain_wgs, fences, trace, d_snap + h, s->ov_chain);
+      s->info.chain_wgs = lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0,
+                                                   s->chain_seq++, s->pricing == 1, chain_wgs, fences, trace, d_snap + h,
+                                                   s->ov_chain);
     }
     s->chain_nb_last = nb;
     HIP_TRY(hipEventRecord(s->ev_ov_chain[h], s->ov_chain));
@@ -883,8 +886,8 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   auto issue_block = [&](int slot) -> int {
     const int nb = block_len(K, max_pivots, decided);
     if (fused && nb > 0) {
-      lpxk::launch_block_chain(s->B, s->R, s->n, s->m, nb, 0, 0, 0, 1, s->chain_seq++, s->pricing == 1, chain_wgs,
-                               fences, trace, d_snap + slot, s->stream);
+      s->info.chain_wgs = lpxk::launch_block_chain(s->B, s->R, s->n, s->m, nb, 0, 0, 0, 1, s->chain_seq++, s->pricing == 1,
+                                                   chain_wgs, fences, trace, d_snap + slot, s->stream);
       s->chain_nb_last = nb;
     } else {
       for (int k = 0; k < nb; k++) {
@@ -966,6 +969,7 @@ extern "C" int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value) {
   if ((key == LPX_OPT_CHAIN_CUS || key == LPX_OPT_SWEEP_CUS) && s->ov_chain && value != s->opt[key])
     return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: the CU-masked stream pair of this handle exists already (set CHAIN_CUS / SWEEP_CUS before the first blocked loop)");
   s->opt[key] = value;
+  if (key == LPX_OPT_CHAIN_FORM) s->B.chain_form = (int)value;
   if (key == LPX_OPT_FUSED) s->B.fused = value != 0;   // which of the two compilations of the kernels the launches take
   if (key == LPX_OPT_UPDATE_U || key == LPX_OPT_UPDATE_ROWS || key == LPX_OPT_NT) apply_layout_options(s);
   return 0;

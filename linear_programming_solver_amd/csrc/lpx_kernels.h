@@ -54,6 +54,7 @@ struct Buffers {
   RatioRow* partial;  // ntiles
   int32_t* perm;      // n + m_global
   LpxCtl* ctl;
+  int chain_form;     // decision kernel of the one-device blocked loop: 0 = k_block_chain_t, 1 = k_block_chain2_t (LPX_OPT_CHAIN_FORM)
   int fused;          // 0: lpxk::plain kernels (two roundings per update, the default); 1: lpxk::fused (LPX_OPT_FUSED)
 };
 
@@ -101,6 +102,7 @@ struct MgPeers {
   int onehop;                              // 1: every shard ships its candidate's ROW with the candidate (one hop per decision)
   double* candrow[kMaxDevices];            // candidate rows [2][kMaxDevices][ld] of every shard
   unsigned long long* arrive2[kMaxDevices];// their arrival words [2][kMaxDevices][kChainMaxWgs]
+  unsigned spin_max;                       // bound of the waits between devices in polls (0: the default, 2^22 = seconds)
 };
 // which kernel swept the bulk of the tableau (lpx_state_info.sweep_kernel)
 enum SweepKernel { kSweepNone = 0, kSweepTiles = 1, kSweepMulti = 2, kSweepSteady = 3, kSweepPipe64 = 4, kSweepDma = 5, kSweepPull = 6, kSweepPull64 = 7 };

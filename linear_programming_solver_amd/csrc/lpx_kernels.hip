@@ -890,7 +890,7 @@ __device__ __forceinline__ void st_agent(int32_t* p, int32_t x) {
 // agent-scope release) arrives, polls (relaxed, bounded) and acquires; the second workgroup barrier holds the other
 // waves until the invalidate has completed.  Returns false when the spin bound was hit (never in a healthy run:
 // it only keeps a bug from hanging the device).  fences: bit 0 = release fence, bit 1 = acquire fence.
-__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* sh_fail, int fences) {
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* sh_fail, int fences, unsigned spin_max) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -902,7 +902,7 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
     unsigned spins = 0;
     while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       LPX_BARRIER_SLEEP;
-      if (++spins > (1u << 22)) { *sh_fail = 1; break; }   // 1: grid barrier
+      if (++spins > spin_max) { *sh_fail = 1; break; }   // 1: grid barrier
     }
     if (fences & 2) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1006,6 +1006,7 @@ struct ChainArgs {
   int onehop;
   double* candrow_peer[kMaxDevices];             // every shard's candidate rows [2][kMaxDevices][ld]
   unsigned long long* arrive2_peer[kMaxDevices]; // every shard's arrival words of the candidate rows [2][kMaxDevices][kChainMaxWgs]
+  unsigned spin_max;    // bound of every wait between workgroups / devices (polls; ~0.5-1 us each): a bug never hangs the GPU
 };
 
 // KB: capacity of one ring half seen by the launch (32, or 64 for blocks of more than 32 pivots — the same code with
@@ -1149,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     const unsigned xtag = P.hand_base + (unsigned)s;  // sequence number of this decision (unique over launches)
     if (P.dbg && lead) P.dbg[s * 5 + 1] = wall_clock64();
     target += (unsigned)G;
-    if (!grid_barrier(P.bar, target, &sh_fail, P.fences)) {
+    if (!grid_barrier(P.bar, target, &sh_fail, P.fences, P.spin_max)) {
       if (lead) { ctl->status = 7 /* LPX_DEVICE_ERROR */; chain_publish(ctl, P.host_snap); }
       return;
     }
@@ -1198,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         unsigned spins = 0;
         while ((unsigned)((g = __hip_atomic_load(&gran[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != xtag) {
           LPX_BARRIER_SLEEP;
-          if (++spins > (1u << 22)) { sh_fail = 1; break; }   // 1: a workgroup's candidate record
+          if (++spins > P.spin_max) { sh_fail = 1; break; }   // 1: a workgroup's candidate record
         }
         sh_part[idx] = (unsigned)g;
       }
@@ -1343,7 +1344,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
         unsigned spins = 0;
         while (__hip_atomic_load(&rec->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xtag) {
           LPX_BARRIER_SLEEP;
-          if (++spins > (1u << 22)) { sh_fail = 2 + 16 * tid; break; }   // 2: a peer's candidate record
+          if (++spins > P.spin_max) { sh_fail = 2 + 16 * tid; break; }   // 2: a peer's candidate record
         }
         if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         theirs.ratio = ld_sys(&rec->ratio);
@@ -1403,7 +1404,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
           unsigned spins = 0;
           while (__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)xtag) {
             LPX_BARRIER_SLEEP;
-            if (++spins > (1u << 22)) { sh_fail = 5 + 16 * tid; break; }   // 5: the winner's candidate-row arrival word
+            if (++spins > P.spin_max) { sh_fail = 5 + 16 * tid; break; }   // 5: the winner's candidate-row arrival word
           }
           if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         }
@@ -1418,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
           unsigned spins = 0;
           while (__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)xtag) {
             LPX_BARRIER_SLEEP;
-            if (++spins > (1u << 22)) { sh_fail = 3 + 16 * tid; break; }   // 3: the owner's arrival word
+            if (++spins > P.spin_max) { sh_fail = 3 + 16 * tid; break; }   // 3: the owner's arrival word
           }
           if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         }
@@ -1529,7 +1530,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
           rec = __hip_atomic_load(P.hand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(rec >> 32) == want) break;
           LPX_BARRIER_SLEEP;
-          if (++spins > (1u << 22)) { sh_fail = 4; break; }   // 4: workgroup 0's hand-off word
+          if (++spins > P.spin_max) { sh_fail = 4; break; }   // 4: workgroup 0's hand-off word
         }
         sh_restart = (int)(unsigned)(rec & 0xffffffffu) - 2;
       }
@@ -1540,7 +1541,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
     }
     if (e_next < 0) {  // no hand-off (Dantzig, narrow tableau) or no candidate in its window: the full exchange
       target += (unsigned)G;
-      if (!grid_barrier(P.bar, target, &sh_fail, P.fences)) {
+      if (!grid_barrier(P.bar, target, &sh_fail, P.fences, P.spin_max)) {
         if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); }
         return;
       }
@@ -1566,6 +1567,399 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
       return;
     }
     e = e_next;
+  }
+}
+
+// ---- k_block_chain2: the same decisions, half the dependent round trips (one device; option chain_form = 1) ---------
+// k_block_chain_t spends a decision in ~8 memory round trips that depend on each other (13-14 us alone, 18-20 us beside
+// a sweep, whatever it computes).  Four of them are not data dependencies of the algorithm:
+//   (1) phase A fetched c[e] and the pending pivots' prow_u[e], met, and only THEN asked for its column entries;
+//   (2) it drained its stores (col_s) before publishing the workgroup's candidate;
+//   (3) phase B fetched the pending pivots' col_u[l], met, and only then asked for its row entries;
+//   (4) workgroup 0 drained its stores (prow_s, c) before publishing the next entering slot.
+// Here a phase asks for everything at once — the few lanes that serve the pending pivots issue their loads FIRST (loads
+// return in order), then every thread its row / column entries and its own ring values; one workgroup meeting later the
+// arithmetic runs — and nothing is drained on the critical path:
+//   * what the NEXT phase A needs of the decision just taken — c[e'] and prow_s[e'] — travels INSIDE workgroup 0's
+//     hand-off record (five self-validating 8-byte granules {32 data bits, sequence tag});
+//   * everything older a later decision reads across workgroups (col_u[l], prow_u[e] of EARLIER decisions) was stored at
+//     least one decision before it is asked for, and every wave passes an s_waitcnt vmcnt(0) (the one in front of the
+//     workgroup meeting of its next phase) before its workgroup publishes anything newer: a candidate record of
+//     decision s+1 implies col_s is visible, a hand-off record of decision s+1 implies prow_s and c of decision s are;
+//   * the stale copies kept for the fix-up (col0, row0) are plain stores: only the next kernel reads them.
+// When workgroup 0 finds no entering slot in its window (2 % of the decisions; always under Dantzig pricing or with
+// fewer than 256 columns) the decision ends as before: drain, grid barrier, every workgroup reduces the candidates, and
+// the next phase A loads c[e] and prow_s[e] from memory.
+// Workgroups of NT = 512 threads (two waves per SIMD, the whole register file): one row / one column per thread covers
+// cfg3 with 33 and cfg4 with 65 workgroups, and the exchange between workgroups shrinks with their number.
+// Arithmetic, ownership, restart logic, ring layout and the bounded spins are those of k_block_chain_t; the two kernels
+// can take turns on one handle (same rings, same hand-off line, tags grow over launches).
+constexpr int kChain2Threads = 256;
+template <int KB, int NT>
+__global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
+  static_assert(KB == 32 || KB == 64, "ring half of 32 or 64 slots");
+  static_assert(NT % 64 == 0 && NT >= 256 && NT >= 2 * KB + 64, "lanes for the pending pivots and the loader lane");
+  __shared__ RatioRow sh_rr[NT / 64];
+  __shared__ unsigned long long sh_mask[2];
+  __shared__ unsigned sh_part[kChainMaxWgs * 8], sh_hand[8];
+  __shared__ double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB], sh_win[2];
+  __shared__ int sh_e[2 * KB], sh_l[2 * KB];
+  __shared__ int sh_fail;
+  const double* __restrict__ A = P.A;
+  const double* __restrict__ b = P.b;
+  const int64_t ld = P.ld, mp = P.mp;
+  const int n = P.n, m = P.m, nb = P.nb, n_old = P.n_old;
+  LpxCtl* const ctl = P.ctl;
+  const int G = gridDim.x, T = G * NT, tid = threadIdx.x, gid = blockIdx.x * NT + tid;
+  const bool lead = gid == 0;
+  constexpr int row0 = 0;   // one device: local row = global row
+  if (tid == 0) {
+    sh_fail = 0;
+    if (P.census) P.census[blockIdx.x] = xcc_id() + 1u;
+  }
+  if (lead) st_agent(reinterpret_cast<int32_t*>(P.bar_next), 0);
+  int e = ctl->e_next;
+  if (ctl->status != kRunning || e < 0 || nb < 1) {
+    if (lead && nb >= 1) P.up[0].do_update = 0;
+    if (lead) chain_publish(ctl, P.host_snap);
+    return;
+  }
+  if (tid < n_old) {
+    const LpxCtl& q = P.up_o[tid];
+    sh_e[tid] = q.e_cur; sh_l[tid] = q.l; sh_p[tid] = q.p; sh_bl[tid] = q.bl;
+  }
+  int64_t pivots = ctl->pivots;
+  const int64_t max_pivots = ctl->max_pivots;
+  double v = ctl->v;
+  int track = ctl->track, parity = ctl->parity;
+  unsigned target = 0;
+  // Column ownership, fixed for the launch.  With the hand-off, workgroup 0 owns slots 0..255 and nothing else (it is
+  // on everybody's critical path); the other workgroups share the rest.  Without it every thread strides over all slots.
+  const bool window = !P.dantzig && ld >= 256 && G > 1;
+  const int jfirst = !window ? gid : (blockIdx.x == 0 ? (tid < 256 ? tid : (int)ld) : 256 + (int)(blockIdx.x - 1) * NT + tid);
+  const int jstep = !window ? T : (blockIdx.x == 0 ? (int)ld : T - NT);
+  const char* const oc_o = reinterpret_cast<const char*>(P.own_col_o);
+  const char* const oc_n = reinterpret_cast<const char*>(P.own_col);
+  const char* const op_o = reinterpret_cast<const char*>(P.own_prow_o);
+  const char* const op_n = reinterpret_cast<const char*>(P.own_prow);
+  const uint32_t mp8_0 = (uint32_t)mp * 8u, ld8_0 = (uint32_t)ld * 8u;   // (launcher: 64 * max(mp, ld) * 8 < 2^32)
+  bool have_rec = false;   // sh_hand[1..4] hold c[e] and prow_{s-1}[e] of the record that named e (uniform)
+  unsigned long long* const hand = P.hand;
+  __syncthreads();
+
+  for (int s = 0; s < nb; ++s) {
+    // ------------------------------------------------------------------ phase A: column e, ratio test
+    if (P.dbg && lead) P.dbg[s * 5 + 0] = wall_clock64();
+    // the ring pitches, made opaque per decision: otherwise the 128 slot offsets of the ring loads are hoisted out of the
+    // decision loop as loop invariants and live (spilled) across it
+    uint32_t mp8 = mp8_0, ld8 = ld8_0;
+    asm volatile("" : "+s"(mp8), "+s"(ld8));
+    const int r_mine = tid & (KB - 1);
+    const bool old_mine = tid < KB;
+    const bool valid_mine = tid < 2 * KB && (old_mine ? r_mine < n_old : r_mine < s);
+    if (tid < 2 * KB) {   // restart pivot of column e: a question to LDS only
+      const unsigned long long mask = __ballot(valid_mine && sh_e[tid] == e);
+      if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
+    }
+    __syncthreads();
+    const int ra = chain_restart<KB>(sh_mask);
+    const int fo_a = ra < 0 ? 0 : (ra < KB ? ra + 1 : n_old);
+    const int fn_a = ra >= KB ? ra - KB + 1 : 0;
+    const bool use_b = P.b_from_tableau && s == 0;
+    // every load of the phase in ONE round trip; the lanes of the pending pivots first
+    double pe_mine = 0.0, pc_mine = 0.0;
+    const bool pe_from_rec = have_rec && tid == KB + s - 1;   // (s >= 1 whenever have_rec)
+    if (valid_mine && !pe_from_rec) pe_mine = ld_agent((old_mine ? P.prow_o : P.prow) + (int64_t)r_mine * ld + e);
+    if (tid == NT - 1 && !have_rec) pc_mine = ld_agent(&P.c[e]);
+    RatioRow best = rr_none();
+    double best_a = 0.0, best_b = 0.0;
+    double a = 0.0, bi = 0.0;
+    double cs[KB], cso[KB];   // this thread's own stores, only the chunks with a live step
+    auto load_row = [&](int i) {
+      const double* src_a = ra < 0 ? &A[(int64_t)i * ld + e]
+                                   : (ra < KB ? &P.own_dvc_o[(int64_t)ra * mp + i] : &P.own_dvc[(int64_t)(ra - KB) * mp + i]);
+      a = *src_a;
+      bi = use_b ? b[i] : P.own_b[i];
+      const uint32_t i8 = (uint32_t)i * 8u;   // uniform base (SGPRs) + one 32-bit lane offset per load: the rings are < 4 GiB
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8)
+        if (LPX_CHAIN_LIVE(r0, fo_a, n_old)) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) cso[r0 + q] = *reinterpret_cast<const double*>(oc_o + ((uint32_t)(r0 + q) * mp8 + i8));
+        }
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8)
+        if (LPX_CHAIN_LIVE(r0, fn_a, s)) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) cs[r0 + q] = *reinterpret_cast<const double*>(oc_n + ((uint32_t)(r0 + q) * mp8 + i8));
+        }
+    };
+    int i = gid;
+    if (i < m) load_row(i);
+    // everything has been asked for; by the time it is here, whatever this wave stored during the previous decision has
+    // long landed: the drain that makes those stores visible before this workgroup publishes anything newer is free
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (valid_mine) sh_pe[tid] = pe_from_rec ? from32(sh_hand[3], sh_hand[4]) : pe_mine;
+    if (tid == NT - 1 && !have_rec) { sh_hand[1] = lo32(pc_mine); sh_hand[2] = hi32(pc_mine); }
+    __syncthreads();
+    while (i < m) {
+      const int ig = row0 + i;
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_A(0, r0, fo_a, n_old, cso)
+      P.col0[(int64_t)s * mp + i] = a;   // the entry the sweep of THIS block will read (for the fix-up: next kernel)
+#pragma unroll
+      for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_A(KB, r0, fn_a, s, cs)
+      st_agent(&P.col[(int64_t)s * mp + i], a);
+      P.own_col[(int64_t)s * mp + i] = a;
+      const double rt = ratio_of(a, bi);
+      if (rt < best.ratio) {  // i ascends per thread: strict < keeps the lowest row among equal ratios
+        best = RatioRow{rt, ig, 0};
+        best_a = a;
+        best_b = bi;
+      }
+      i += T;
+      __builtin_amdgcn_sched_barrier(0);   // (the next pass's loads stay behind this pass's arithmetic: one set of registers)
+      if (i < m) load_row(i);   // (tableaus taller than the grid: a round trip per further row)
+    }
+    const double pc = from32(sh_hand[1], sh_hand[2]);   // c[e]: from the record that named e, or the loader lane
+    const unsigned xtag = P.hand_base + (unsigned)s;    // sequence number of this decision (unique over launches)
+    {
+      const RatioRow w = rr_block_min(best, sh_rr);
+      if (w.row != INT_MAX && best.row == w.row) { sh_win[0] = best_a; sh_win[1] = best_b; }
+      __syncthreads();
+      const double wa = (w.row != INT_MAX) ? sh_win[0] : 0.0, wb = (w.row != INT_MAX) ? sh_win[1] : 0.0;
+      if (P.dbg && lead) P.dbg[s * 5 + 1] = wall_clock64();
+      // the workgroup's candidate as seven tagged granules — NOT behind a drain: nobody reads col_s across workgroups
+      // before decision s + 1, and every wave has passed a vmcnt(0) (the meeting above) since its stores of decision s - 1
+      unsigned long long* const gran = reinterpret_cast<unsigned long long*>(P.partA) + (size_t)(s & 1) * kChainMaxWgs * 8;
+      if (tid < 7) {
+        const unsigned d = tid == 0 ? lo32(w.ratio) : tid == 1 ? hi32(w.ratio) : tid == 2 ? lo32(wa) : tid == 3 ? hi32(wa)
+                         : tid == 4 ? lo32(wb) : tid == 5 ? hi32(wb) : (unsigned)w.row;
+        __hip_atomic_store(&gran[blockIdx.x * 8 + tid], ((unsigned long long)xtag << 32) | d, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int idx = tid; idx < G * 8; idx += NT) {   // one lane per granule of every workgroup's record
+        if ((idx & 7) == 7) continue;
+        unsigned long long g;
+        unsigned spins = 0;
+        while ((unsigned)((g = __hip_atomic_load(&gran[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != xtag) {
+          LPX_BARRIER_SLEEP;
+          if (++spins > P.spin_max) { sh_fail = 1; break; }   // 1: a workgroup's candidate record
+        }
+        sh_part[idx] = (unsigned)g;
+      }
+      if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+      if (sh_fail) {
+        if (lead) { ctl->status = 7 /* LPX_DEVICE_ERROR */; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); }
+        return;
+      }
+    }
+    if (P.dbg && lead) P.dbg[s * 5 + 2] = wall_clock64();
+
+    // ------------------------------------------------------------------ phase B: the leaving row
+    RatioRow mine = rr_none();
+    double mine_a = 0.0, mine_b = 0.0;
+    if (tid < G) {
+      const unsigned* q = &sh_part[tid * 8];
+      mine.ratio = from32(q[0], q[1]);
+      mine_a = from32(q[2], q[3]);
+      mine_b = from32(q[4], q[5]);
+      mine.row = (int)q[6];
+    }
+    const RatioRow w = rr_block_min(mine, sh_rr);
+    if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
+    __syncthreads();
+    if (w.row == INT_MAX || !(w.ratio < kInf)) {  // getLeaving() == -1: unbounded
+      if (lead) {
+        ctl->status = 1; ctl->do_update = 0; ctl->l = -1; ctl->ratio = w.ratio; P.up[s].do_update = 0;
+        chain_publish(ctl, P.host_snap);
+      }
+      return;
+    }
+    if (max_pivots >= 0 && pivots >= max_pivots) {
+      if (lead) {
+        ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; P.up[s].do_update = 0;
+        chain_publish(ctl, P.host_snap);
+      }
+      return;
+    }
+    const int l = w.row;
+    const double p = sh_win[0], raw_b = sh_win[1];
+    if (p == 0.0) {  // ArithmeticException in the reference, LPState.java:139
+      if (lead) { ctl->status = 8; ctl->do_update = 0; P.up[s].do_update = 0; chain_publish(ctl, P.host_snap); }
+      return;
+    }
+    if (tid < 2 * KB) {   // restart pivot of row l: LDS only
+      const unsigned long long mask = __ballot(valid_mine && sh_l[tid] == l);
+      if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
+    }
+    __syncthreads();
+    const int rb = chain_restart<KB>(sh_mask);
+    const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
+    const int fn_b = rb >= KB ? rb - KB + 1 : 0;
+    // again everything in one round trip: col_u[l] of the pending pivots first, then the thread's column of row l
+    double cs_mine = 0.0;
+    if (valid_mine) cs_mine = ld_agent((old_mine ? P.col_o : P.col) + (int64_t)r_mine * mp + l);
+    const double bl = __ddiv_rn(raw_b, p);                                         // :146
+    const double inv_p = __ddiv_rn(1.0, p);                                        // :139
+    RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
+    double rec_c = 0.0, rec_pr = 0.0;   // workgroup 0: what its thread of slot j would put into the hand-off record
+    const double* rowl = A + (int64_t)l * ld;
+    double x = 0.0, cj = 0.0;
+    double prv[KB], prvo[KB];   // this thread's own stores, live chunks only
+    auto load_col = [&](int j) {
+      cj = ld_agent(&P.c[j]);  // this thread's own store (or the initial value)
+      x = 0.0;
+      if (j < n) {
+        const double* src_x = rb < 0 ? &rowl[j]
+                                     : (rb < KB ? &P.own_prow_o[(int64_t)rb * ld + j] : &P.own_prow[(int64_t)(rb - KB) * ld + j]);
+        x = *src_x;
+        const uint32_t j8 = (uint32_t)j * 8u;
+#pragma unroll
+        for (int r0 = 0; r0 < KB; r0 += 8)
+          if (LPX_CHAIN_LIVE(r0, fo_b, n_old)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) prvo[r0 + q] = *reinterpret_cast<const double*>(op_o + ((uint32_t)(r0 + q) * ld8 + j8));
+          }
+#pragma unroll
+        for (int r0 = 0; r0 < KB; r0 += 8)
+          if (LPX_CHAIN_LIVE(r0, fn_b, s)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) prv[r0 + q] = *reinterpret_cast<const double*>(op_n + ((uint32_t)(r0 + q) * ld8 + j8));
+          }
+      }
+    };
+    int j = jfirst;
+    if (j < (int)ld) load_col(j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as in phase A: also the free drain of this wave's earlier stores)
+    if (valid_mine) {
+      sh_cs[tid] = cs_mine;
+      sh_dv[tid] = -__ddiv_rn(cs_mine, sh_p[tid]);
+    }
+    __syncthreads();
+    while (j < (int)ld) {
+      if (j < n) {
+#pragma unroll
+        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(0, r0, fo_b, n_old, prvo)
+        P.row0[(int64_t)s * ld + j] = x;   // the row as the sweep of this block will read it (for the fix-up: next kernel)
+#pragma unroll
+        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(KB, r0, fn_b, s, prv)
+      }
+      double cn, pr;
+      if (j == e) {
+        pr = inv_p;
+        cn = -__ddiv_rn(pc, p);                                                    // :172
+      } else {
+        pr = __ddiv_rn(x, p);                                                      // :144
+        cn = submul(cj, pc, pr);                                                   // :177
+      }
+      st_agent(&P.prow[(int64_t)s * ld + j], pr);
+      P.own_prow[(int64_t)s * ld + j] = pr;
+      st_agent(&P.c[j], cn);
+      if (j < n && cn > kEps) {
+        const RatioRow k2{P.dantzig ? -cn : 0.0, j, 0};
+        cand = rr_min(cand, k2);
+      }
+      rec_c = cn;
+      rec_pr = pr;
+      j += jstep;
+      __builtin_amdgcn_sched_barrier(0);
+      if (j < (int)ld) load_col(j);
+    }
+    if (window && blockIdx.x == 0) {
+      // Workgroup 0 has finished slots 0..255.  Under the first-positive rule the next entering slot is the lowest one
+      // with c > eps: if there is one among them it is the answer, and the thread that owns it publishes {slot, c[slot],
+      // prow_s[slot]} — all the next phase A needs of this decision — as five tagged granules, no drain.  No candidate
+      // here: "none", and everybody takes the grid barrier below.
+      const RatioRow w0 = rr_block_min(cand, sh_rr);
+      const unsigned long long tg = (unsigned long long)xtag << 32;
+      if (w0.row == INT_MAX ? tid == 0 : tid == w0.row) {
+        const bool none = w0.row == INT_MAX;
+        __hip_atomic_store(&hand[1], tg | (none ? 0u : lo32(rec_c)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hand[2], tg | (none ? 0u : hi32(rec_c)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hand[3], tg | (none ? 0u : lo32(rec_pr)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hand[4], tg | (none ? 0u : hi32(rec_pr)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hand[0], tg | (unsigned)((none ? -2 : w0.row) + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // the row owners add pivot s to their two running columns: the entering column after the pivot (what a later
+    // decision restarts from) and b — after the columns, so that workgroup 0 publishes the entering slot first
+    for (int i = gid; i < m; i += T) {
+      const double colv = P.own_col[(int64_t)s * mp + i];
+      const double bcur = use_b ? b[i] : P.own_b[i];
+      P.own_dvc[(int64_t)s * mp + i] = (row0 + i == l) ? inv_p : -__ddiv_rn(colv, p);    // :157 / :139
+      P.own_b[i] = (row0 + i == l) ? bl : submul(bcur, colv, bl);                        // :146 / :164
+    }
+    {
+      const RatioRow w2 = rr_block_min(cand, sh_rr);
+      if (tid == 0) {
+        st_agent(&P.partB[blockIdx.x].ratio, w2.ratio);
+        st_agent(&P.partB[blockIdx.x].row, w2.row);
+        sh_e[KB + s] = e; sh_l[KB + s] = l; sh_p[KB + s] = p; sh_bl[KB + s] = bl;
+      }
+    }
+    if (lead) {
+      v = addmul(v, bl, pc);                                                       // :171
+      const int32_t perm_e = P.perm[e], perm_l = P.perm[n + l];                    // exchangeIndexes :311-320
+      P.perm[e] = perm_l;
+      P.perm[n + l] = perm_e;
+      if (track >= 0) {                                                            // LPSolver.java:151-155
+        if (e == track) track = l + n;
+        else if (l + n == track) track = e;
+      }
+      LpxCtl& up = P.up[s];
+      up.p = p; up.bl = bl; up.e_cur = e; up.l = l; up.e_next = -1; up.parity = 0; up.do_update = 1;
+    }
+    if (P.dbg && lead) P.dbg[s * 5 + 3] = wall_clock64();
+    int e_next = -2;
+    have_rec = false;
+    if (window) {  // five lanes per workgroup wait for workgroup 0's record (bounded, like the barrier)
+      if (tid < 5) {
+        unsigned long long rec = 0;
+        unsigned spins = 0;
+        for (;;) {
+          rec = __hip_atomic_load(&hand[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(rec >> 32) == xtag) break;
+          LPX_BARRIER_SLEEP;
+          if (++spins > P.spin_max) { sh_fail = 4; break; }   // 4: workgroup 0's hand-off record
+        }
+        sh_hand[tid] = (unsigned)rec;
+      }
+      __syncthreads();
+      if (sh_fail) { if (lead) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
+      e_next = (int)sh_hand[0] - 2;
+      have_rec = e_next >= 0;
+    }
+    if (e_next < 0) {  // no hand-off (Dantzig, narrow tableau) or no candidate in its window: the full exchange
+      target += (unsigned)G;
+      if (!grid_barrier(P.bar, target, &sh_fail, P.fences, P.spin_max)) {
+        if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); }
+        return;
+      }
+      RatioRow m2 = rr_none();
+      if (tid < G) { m2.ratio = ld_agent(&P.partB[tid].ratio); m2.row = ld_agent(&P.partB[tid].row); }
+      const RatioRow w3 = rr_block_min(m2, sh_rr);
+      e_next = (w3.row == INT_MAX) ? -1 : w3.row;
+    }
+    if (P.dbg && lead) P.dbg[s * 5 + 4] = wall_clock64();
+    pivots += 1;
+    parity ^= 1;
+    if (lead) {
+      ctl->v = v; ctl->p = p; ctl->bl = bl; ctl->pc = pc; ctl->ratio = w.ratio;
+      ctl->e_cur = e; ctl->l = l; ctl->e_next = e_next; ctl->parity = parity; ctl->pivots = pivots;
+      ctl->track = track; ctl->do_update = 1;
+      if (e_next < 0) {
+        ctl->status = 0 /* LPX_OPTIMAL once the sweep has applied this pivot */;
+        if (s + 1 < nb) P.up[s + 1].do_update = 0;  // the block ends here: the sweep counts leading valid slots
+      }
+    }
+    if (e_next < 0 || s + 1 == nb) {
+      if (lead) chain_publish(ctl, P.host_snap);
+      return;
+    }
+    e = e_next;
+    __syncthreads();   // sh_e[KB + s] .. and sh_hand are read by the next decision; sh_mask / sh_win are rewritten
   }
 }
 #undef LPX_CHAIN_STEP_A
@@ -3247,7 +3641,7 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 // half / old_half: which half of the 2*kBlockMax-slot rings this block / the not-yet-swept previous block uses
 // (n_old = 0: no such block, the tableau read is current); seq: launch counter of the loop (barrier counters
 // alternate); B.A / B.b: the tableau version to read.
-void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
+int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
                         int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
                         hipStream_t s, const MgPeers* mg) {
   // fences = 2 (the engine's default), acquire only: everything that crosses workgroups inside the launch is stored
@@ -3259,6 +3653,15 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   const int64_t work = std::max<int64_t>(m, B.ld);
   int G = wgs > 0 ? wgs : (int)std::min<int64_t>(64, std::max<int64_t>(1, (work + 511) / 512));
   G = std::max(1, std::min(G, kChainMaxWgs));
+  // chain_form 1 (one device): k_block_chain2, workgroups of kChain2Threads — one row / one column per thread needs
+  // fewer of them (+1: workgroup 0 serves the hand-off window only); never more than the caller found resident (wgs
+  // counts workgroups of ONE per CU, which holds for both kernels)
+  const bool form2 = mg == nullptr && B.chain_form == 1;
+  if (form2) {
+    const int64_t rows_wgs = (m + kChain2Threads - 1) / kChain2Threads;
+    const int64_t cols_wgs = (std::max<int64_t>(B.ld - 256, 0) + kChain2Threads - 1) / kChain2Threads + 1;
+    G = (int)std::max<int64_t>(1, std::min<int64_t>(G, std::max(rows_wgs, cols_wgs)));
+  }
   const int64_t K = kBlockMax;
   const bool wide = nb > 32 || n_old > 32;   // a block of more than 32 pivots on either side: the 64-slot form
   ChainArgs P{};
@@ -3277,6 +3680,7 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
   P.hand = reinterpret_cast<unsigned long long*>(R.chain_bar + 64);   // its own 128-byte line
   P.hand_base = (unsigned)(seq + 1) * 64u;  // > any sequence of earlier launches (<= kBlockMax decisions each)
   P.dantzig = dantzig; P.fences = fences; P.host_snap = host_snap; P.dbg = trace ? R.chain_dbg : nullptr;
+  P.spin_max = (mg && mg->spin_max) ? mg->spin_max : (1u << 22);
   P.census = R.census;
   if (mg) {
     P.shard_row0 = mg->row0; P.m_global = mg->m_global; P.n_dev = mg->n_dev; P.dev = mg->dev;
@@ -3291,11 +3695,16 @@ void launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int 
     }
     if (wide) hipLaunchKernelGGL((k_block_chain_t<true, 64>), dim3(G), dim3(256), 0, s, P);
     else hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(G), dim3(256), 0, s, P);
+  } else if (form2) {
+    P.m_global = m; P.n_dev = 1;
+    if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads>), dim3(G), dim3(kChain2Threads), 0, s, P);
+    else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads>), dim3(G), dim3(kChain2Threads), 0, s, P);
   } else {
     P.m_global = m; P.n_dev = 1;
     if (wide) hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(G), dim3(256), 0, s, P);
     else hipLaunchKernelGGL((k_block_chain_t<false, 32>), dim3(G), dim3(256), 0, s, P);
   }
+  return G;
 }
 
 // The runtime prepares a kernel for a device the first time it is LAUNCHED (looking the function up does not do it;
@@ -3366,21 +3775,26 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
   ChainArgs P{};   // nb = 0: every workgroup returns after reading the loop state (no barrier, nothing published)
   P.ctl = B.ctl; P.up = R.up; P.nb = 0;
   P.bar = R.chain_bar; P.bar_next = R.chain_bar + 32;
+  P.spin_max = 1u << 22;
   hipLaunchKernelGGL((k_block_chain_t<false, 32>), dim3(1), dim3(256), 0, s, P);
   hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(1), dim3(256), 0, s, P);
   hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(1), dim3(256), 0, s, P);
+  hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads>), dim3(1), dim3(kChain2Threads), 0, s, P);
+  hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads>), dim3(1), dim3(kChain2Threads), 0, s, P);
   (void)hipGetLastError();
 }
 
 int chain_blocks_per_cu() {
   int nb = 0;
   int nw = 0;
+  int n2 = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_block_chain_t<true, 32>), 256, 0) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, (k_block_chain_t<false, 64>), 256, 0) != hipSuccess) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, (k_block_chain_t<false, 64>), 256, 0) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (k_block_chain2_t<64, kChain2Threads>), kChain2Threads, 0) != hipSuccess) {
     (void)hipGetLastError();
-    nb = nw = 1;
+    nb = nw = n2 = 1;
   }
-  return std::max(1, std::min(nb, nw));
+  return std::max(1, std::min(std::min(nb, nw), n2));
 }
 
 template <int K>

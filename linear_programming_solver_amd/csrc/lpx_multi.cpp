@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -30,6 +31,8 @@ struct lpx_multi {
   int seq = 0;                        // decision-kernel launches so far (the SAME number on every shard: tags)
   bool distinct_devices = false;
   bool fences_chosen = false;         // lpx_multi_set_option(LPX_OPT_CHAIN_FENCES) was called: honour it
+  unsigned spin_max = 0;              // bound of the waits between devices (polls), sized from the warm launches below
+  double first_launch_us = 0.0;       // slowest launch + completion of a full-grid decision kernel that decides nothing
 };
 
 static int shard_of(const lpx_multi* M, int32_t row) {
@@ -189,6 +192,7 @@ static lpxk::MgPeers peers_of(const lpx_multi* M, int r) {
     P.candrow[d] = M->sh[d]->R.mg_candrow;
     P.arrive2[d] = M->sh[d]->R.mg_arrive2;
   }
+  P.spin_max = M->spin_max;
   P.onehop = M->sh[0]->opt[LPX_OPT_MULTI_ONEHOP] != 0 && M->sh[0]->R.mg_candrow != nullptr;
   M->sh[r]->info.multi_onehop = P.onehop;
   return P;
@@ -410,6 +414,29 @@ extern "C" int lpx_multi_simplex_loop(lpx_multi* M, int64_t max_pivots, int64_t*
     wgs = std::min(wgs, clamp_chain_wgs(M->sh[r], want, cus));
   }
   for (int r = 0; r < G; r++) { M->sh[r]->info.chain_wgs = wgs; M->sh[r]->info.overlapped = 0; M->sh[r]->info.chain_stream_masked = 0; }
+  if (M->spin_max == 0) {
+    // First use of this device set.  The decision kernels of a block wait for each other, and ONE host thread launches
+    // them device after device: a kernel's first launch on a device (code object load, queue creation) must not fall
+    // inside such a wait.  So every device first runs the very kernel at the very grid with nothing to decide (nb = 0:
+    // every workgroup returns after reading the loop state), timed from launch to completion and waited for; the
+    // slowest one sizes the bound of the cross-device waits: 128 x that time in polls of >= ~0.5 us each, never below
+    // the default 2^22 polls (seconds).
+    double worst_us = 0.0;
+    for (int r = 0; r < G; r++) {
+      lpx_state* s = M->sh[r];
+      HIP_TRY(hipSetDevice(M->device[r]));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      lpxk::MgPeers P = peers_of(M, r);
+      const auto t0 = std::chrono::steady_clock::now();
+      lpxk::launch_block_chain(s->B, s->R, s->n, s->m, 0, 0, 0, 0, 1, M->seq, M->sh[0]->pricing == 1, wgs, 3, false, nullptr,
+                               s->stream, &P);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      worst_us = std::max(worst_us, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+    M->first_launch_us = worst_us;
+    M->spin_max = (unsigned)std::min<double>(4.0e9, std::max<double>((double)(1u << 22), 128.0 * worst_us));
+  }
   // across real devices the conservative barrier form (release + acquire around every exchange) unless the caller
   // chose one with lpx_multi_set_option: the fence-free form is validated inside one device only
   const int fences = (M->distinct_devices && !M->fences_chosen) ? 3 : (int)M->sh[0]->opt[LPX_OPT_CHAIN_FENCES];
