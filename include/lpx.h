@@ -176,6 +176,11 @@ const char* lpx_sweep_kernel_name(int32_t code);
  * start, phase A done, barrier passed, phase B done, next entering slot known.  ticks has room for 5 * cap
  * values; *ndecisions = decisions of the last launch that are present. */
 int lpx_state_read_chain_trace(lpx_state* s, int64_t* ticks, int32_t cap, int32_t* ndecisions);
+/* The same with every stamp the decision kernel keeps: *stamps per decision (k_block_chain2_t, option chain_form = 1: 8 —
+ * start, phase A's loads arrived, candidate published, every candidate read, phase B's loads arrived, hand-off record
+ * stored, phase B done, next entering slot known; k_block_chain_t: the 5 above).  ticks has room for 16 * cap values
+ * (a diagnostic build keeps 16 stamps). */
+int lpx_state_read_chain_trace_fine(lpx_state* s, int64_t* ticks, int32_t cap, int32_t* ndecisions, int32_t* stamps);
 
 /* Pivots per pass over the tableau in lpx_simplex_loop / lpx_solve ("blocked pivoting"): K pivot decisions are
  * taken from the not-yet-updated tableau (each needs one column and one row, recovered by the pending pivots'

@@ -102,6 +102,7 @@ SYMBOLS = [
     ("lpx_state_get_info", C.c_int, [C.c_void_p, C.POINTER(StateInfo)]),
     ("lpx_sweep_kernel_name", C.c_char_p, [C.c_int32]),
     ("lpx_state_read_chain_trace", C.c_int, [C.c_void_p, i64p, C.c_int32, ip]),
+    ("lpx_state_read_chain_trace_fine", C.c_int, [C.c_void_p, i64p, C.c_int32, ip, ip]),
     ("lpx_get_entering", C.c_int, [C.c_void_p, ip]),
     ("lpx_get_leaving", C.c_int, [C.c_void_p, C.c_int32, ip, dp]),
     ("lpx_pivot", C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

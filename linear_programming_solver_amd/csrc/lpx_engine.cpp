@@ -79,7 +79,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_SWEEP_CUS", 0, 0, 256},           // LPX_OPT_SWEEP_CUS
     {"LPX_CHAIN_CUS", 0, 0, 16},            // LPX_OPT_CHAIN_CUS
     {"LPX_FUSED", 0, 0, 1},                 // LPX_OPT_FUSED
-    {"LPX_CHAIN_FORM", 0, 0, 1},            // LPX_OPT_CHAIN_FORM
+    {"LPX_CHAIN_FORM", 1, 0, 1},            // LPX_OPT_CHAIN_FORM
 };
 
 static const int64_t* env_defaults() {
@@ -549,8 +549,8 @@ static int build_block_ring(lpx_state* s) {
   HIP_TRY(hipMalloc((void**)&s->R.chain_own_b, (size_t)mp * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.chain_own_col, 0, K * (size_t)mp * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.chain_own_prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
-  HIP_TRY(hipMalloc((void**)&s->R.chain_dbg, 5 * lpxk::kBlockMax * sizeof(long long)));
-  HIP_TRY(hipMemsetAsync(s->R.chain_dbg, 0, 5 * lpxk::kBlockMax * sizeof(long long), s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.chain_dbg, 16 * lpxk::kBlockMax * sizeof(long long)));   // 5 (k_block_chain_t) or 8 stamps per decision
+  HIP_TRY(hipMemsetAsync(s->R.chain_dbg, 0, 16 * lpxk::kBlockMax * sizeof(long long), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.census, (lpxk::kChainMaxWgs + 2 + 1200) * sizeof(unsigned)));   // + room for diagnostic builds
   HIP_TRY(hipMemsetAsync(s->R.census, 0, (lpxk::kChainMaxWgs + 2 + 1200) * sizeof(unsigned), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.zeros, 256));
@@ -701,6 +701,9 @@ static int chain_cus_per_xcd(const lpx_state* s, int per_xcd) {
   const int64_t work = std::max<int64_t>(s->m, s->B.ld);
   const double bytes = 8.0 * (double)s->m * (double)s->B.ld;
   if (!s->multi_shard && work > 8192 && bytes <= 1.5 * 1073741824.0) k = 8;
+  // fused arithmetic: the sweep is bound by its memory pass and keeps its time on 192 CUs (cfg4: 1.548 vs 1.544 ms,
+  // profiles/r04_arith_grid_cfg4_a.txt), and one row per thread halves the decisions' phase A at 32768 rows
+  if (!s->multi_shard && work > 8192 && s->B.fused) k = 8;
   // Multiples of 4 only: workgroups are dealt round the four shader engines of an XCD, so the reserved CUs must be the
   // same number on each of them — with 6 per XCD (2 + 2 + 1 + 1) the 48-workgroup grid was not resident (measured:
   // bounded wait -> LPX_DEVICE_ERROR; likewise one extra CU on one XCD, profiles/r03_decision_passes.txt).
@@ -1017,16 +1020,45 @@ extern "C" int lpx_debug_read_census(lpx_state* s, uint32_t* out, int32_t count)
   return hipMemcpy(out, s->R.census, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : LPX_DEVICE_ERROR;
 }
 
+// stamps per decision the decision kernel of this handle writes: k_block_chain_t 5, k_block_chain2_t 8
+#ifdef LPX_CHAIN2_FINE
+static int chain_trace_stride(const lpx_state* s) { return (s->B.chain_form == 1 && !s->multi_shard) ? 16 : 5; }
+#else
+static int chain_trace_stride(const lpx_state* s) { return (s->B.chain_form == 1 && !s->multi_shard) ? 8 : 5; }
+#endif
+
 extern "C" int lpx_state_read_chain_trace(lpx_state* s, int64_t* ticks, int32_t cap, int32_t* ndecisions) {
   if (!s || !ticks || cap < 0 || !ndecisions) return fail(LPX_BAD_ARGUMENT, "lpx_state_read_chain_trace: bad argument");
   *ndecisions = 0;
   if (!s->R.chain_dbg || s->opt[LPX_OPT_CHAIN_TRACE] == 0) return 0;
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipStreamSynchronize(s->stream));
-  long long h[5 * lpxk::kBlockMax];
+  long long h[16 * lpxk::kBlockMax];
   HIP_TRY(hipMemcpy(h, s->R.chain_dbg, sizeof h, hipMemcpyDeviceToHost));
   const int nd = std::min<int>(std::min<int>(cap, s->chain_nb_last), lpxk::kBlockMax);
-  for (int k = 0; k < 5 * nd; k++) ticks[k] = h[k];
+  // the five stamps of the documented interface; k_block_chain2 keeps eight (lpx_state_read_chain_trace_fine)
+  static const int pick8[5] = {0, 2, 3, 6, 7};
+  const int st = chain_trace_stride(s);
+  for (int d = 0; d < nd; d++)
+    for (int k = 0; k < 5; k++) ticks[5 * d + k] = h[st * d + (st >= 8 ? pick8[k] : k)];
+  *ndecisions = nd;
+  return 0;
+}
+
+// k_block_chain2_t's eight stamps per decision (100 MHz ticks): start, phase A's loads here, candidate published,
+// every candidate read, phase B's loads here, hand-off record stored, phase B done, next entering slot known.
+// *stamps = stamps per decision present (8, or 5 as lpx_state_read_chain_trace for k_block_chain_t).
+extern "C" int lpx_state_read_chain_trace_fine(lpx_state* s, int64_t* ticks, int32_t cap, int32_t* ndecisions, int32_t* stamps) {
+  if (!s || !ticks || cap < 0 || !ndecisions || !stamps) return fail(LPX_BAD_ARGUMENT, "lpx_state_read_chain_trace_fine: bad argument");
+  *ndecisions = 0;
+  *stamps = chain_trace_stride(s);
+  if (!s->R.chain_dbg || s->opt[LPX_OPT_CHAIN_TRACE] == 0) return 0;
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  long long h[16 * lpxk::kBlockMax];
+  HIP_TRY(hipMemcpy(h, s->R.chain_dbg, sizeof h, hipMemcpyDeviceToHost));
+  const int nd = std::min<int>(std::min<int>(cap, s->chain_nb_last), lpxk::kBlockMax);
+  for (int k = 0; k < *stamps * nd; k++) ticks[k] = h[k];
   *ndecisions = nd;
   return 0;
 }

@@ -1007,6 +1007,8 @@ struct ChainArgs {
   double* candrow_peer[kMaxDevices];             // every shard's candidate rows [2][kMaxDevices][ld]
   unsigned long long* arrive2_peer[kMaxDevices]; // every shard's arrival words of the candidate rows [2][kMaxDevices][kChainMaxWgs]
   unsigned spin_max;    // bound of every wait between workgroups / devices (polls; ~0.5-1 us each): a bug never hangs the GPU
+  int diag;             // k_block_chain2 diagnostics (LPX_CHAIN_DIAG, timing experiments only — results are wrong): bit 0 = read the
+                        // entering column from CONTIGUOUS addresses (what a column-major mirror of the window would cost)
 };
 
 // KB: capacity of one ring half seen by the launch (32, or 64 for blocks of more than 32 pivots — the same code with
@@ -1570,49 +1572,107 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
   }
 }
 
-// ---- k_block_chain2: the same decisions, half the dependent round trips (one device; option chain_form = 1) ---------
-// k_block_chain_t spends a decision in ~8 memory round trips that depend on each other (13-14 us alone, 18-20 us beside
-// a sweep, whatever it computes).  Four of them are not data dependencies of the algorithm:
-//   (1) phase A fetched c[e] and the pending pivots' prow_u[e], met, and only THEN asked for its column entries;
-//   (2) it drained its stores (col_s) before publishing the workgroup's candidate;
-//   (3) phase B fetched the pending pivots' col_u[l], met, and only then asked for its row entries;
-//   (4) workgroup 0 drained its stores (prow_s, c) before publishing the next entering slot.
-// Here a phase asks for everything at once — the few lanes that serve the pending pivots issue their loads FIRST (loads
-// return in order), then every thread its row / column entries and its own ring values; one workgroup meeting later the
-// arithmetic runs — and nothing is drained on the critical path:
-//   * what the NEXT phase A needs of the decision just taken — c[e'] and prow_s[e'] — travels INSIDE workgroup 0's
-//     hand-off record (five self-validating 8-byte granules {32 data bits, sequence tag});
-//   * everything older a later decision reads across workgroups (col_u[l], prow_u[e] of EARLIER decisions) was stored at
-//     least one decision before it is asked for, and every wave passes an s_waitcnt vmcnt(0) (the one in front of the
-//     workgroup meeting of its next phase) before its workgroup publishes anything newer: a candidate record of
-//     decision s+1 implies col_s is visible, a hand-off record of decision s+1 implies prow_s and c of decision s are;
-//   * the stale copies kept for the fix-up (col0, row0) are plain stores: only the next kernel reads them.
+// ---- k_block_chain2: the same decisions on a shorter critical path (one device; option chain_form = 1) --------------
+// k_block_chain_t spends a decision in ~8 dependent memory round trips and ~3 000 instructions that a lone wave per SIMD
+// executes one after the other (13-14 us alone, 18-20 us beside a sweep, whatever it computes).  What is not a data
+// dependency of the algorithm is taken off that path here:
+//   round trips  A phase asks for everything at once — the few lanes that serve the pending pivots issue their loads
+//                FIRST (loads return in order), then every thread its row / column entry and its own ring values; one
+//                workgroup meeting later the arithmetic runs.  Nothing is drained in front of a publication: what the
+//                NEXT phase A needs of the decision just taken — c[e'] and prow_s[e'] — travels INSIDE workgroup 0's
+//                hand-off record (five self-validating 8-byte granules {32 data bits, sequence tag}); everything older a
+//                later decision reads across workgroups (col_u[l], prow_u[e] of EARLIER decisions) was stored at least
+//                one decision before it is asked for, and every wave passes an s_waitcnt vmcnt(0) (in front of the
+//                meeting of its next phase, when its loads are here anyway) before its workgroup publishes anything
+//                newer: a candidate record of decision s+1 implies col_s is visible, a hand-off record of decision s+1
+//                implies prow_s and c of decision s are.  The stale copies kept for the fix-up (col0, row0) are plain
+//                stores: only the next kernel reads them.
+//   instructions wave minima by DPP butterflies + four v_readlane instead of six rounds of LDS shuffles; the pending
+//                pivots' parameters come from LDS one chunk of eight AHEAD of the arithmetic that uses them, as 16-byte
+//                reads; a chunk whose eight steps are all live carries no per-step predicate.
+//   workgroup 0  (the one everybody waits for) only does what the hand-off needs: the loop state (v, perm, the ring's
+//                parameter block, the host's snapshot) is kept by the LAST workgroup's first thread, the candidates for
+//                the rare full exchange are reduced only when that exchange happens, and the column a later restart
+//                starts from (-(col_s / p_s)) is computed when a restart needs it, not after every decision.
 // When workgroup 0 finds no entering slot in its window (2 % of the decisions; always under Dantzig pricing or with
-// fewer than 256 columns) the decision ends as before: drain, grid barrier, every workgroup reduces the candidates, and
-// the next phase A loads c[e] and prow_s[e] from memory.
-// Workgroups of NT = 512 threads (two waves per SIMD, the whole register file): one row / one column per thread covers
-// cfg3 with 33 and cfg4 with 65 workgroups, and the exchange between workgroups shrinks with their number.
-// Arithmetic, ownership, restart logic, ring layout and the bounded spins are those of k_block_chain_t; the two kernels
-// can take turns on one handle (same rings, same hand-off line, tags grow over launches).
+// fewer than 256 columns) the decision ends as in k_block_chain_t: drain, grid barrier, every workgroup reduces the
+// candidates, and the next phase A loads c[e] and prow_s[e] from memory.
+// Arithmetic, ownership, restart logic, ring layout and the bounded spins are those of k_block_chain_t (own_dvc is not
+// used); the kernels must not take turns INSIDE one loop (the private ring copies differ in that), between loops they may.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  return __hiloint2double(dpp_i32<CTRL>(__double2hiint(x)), dpp_i32<CTRL>(__double2loint(x)));
+}
+__device__ __forceinline__ double lane_f64(double x, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+// Lexicographic (ratio, row) minimum of a wave, valid in EVERY lane.  Butterflies inside the rows of 16 lanes (quad
+// permutes, half mirror, mirror: each lane ends with its row's minimum), the four rows by v_readlane.  Rows are distinct
+// (or INT_MAX = none); equal ratios -> the lowest row, as rr_min.
+__device__ __forceinline__ RatioRow rr_wave_min_all(RatioRow x) {
+  double r = x.ratio;
+  { const double o = dpp_f64<0xB1>(r); r = o < r ? o : r; }     // quad_perm [1,0,3,2]
+  { const double o = dpp_f64<0x4E>(r); r = o < r ? o : r; }     // quad_perm [2,3,0,1]
+  { const double o = dpp_f64<0x141>(r); r = o < r ? o : r; }    // row_half_mirror
+  { const double o = dpp_f64<0x140>(r); r = o < r ? o : r; }    // row_mirror
+  const double r0 = lane_f64(r, 0), r1 = lane_f64(r, 16), r2 = lane_f64(r, 32), r3 = lane_f64(r, 48);
+  const double ra = r1 < r0 ? r1 : r0, rb = r3 < r2 ? r3 : r2;
+  const double rmin = rb < ra ? rb : ra;
+  int row = (x.ratio == rmin) ? x.row : INT_MAX;
+  row = min(row, dpp_i32<0xB1>(row));
+  row = min(row, dpp_i32<0x4E>(row));
+  row = min(row, dpp_i32<0x141>(row));
+  row = min(row, dpp_i32<0x140>(row));
+  const int q = min(min(__builtin_amdgcn_readlane(row, 0), __builtin_amdgcn_readlane(row, 16)),
+                    min(__builtin_amdgcn_readlane(row, 32), __builtin_amdgcn_readlane(row, 48)));
+  return RatioRow{rmin, q, 0};
+}
+// Workgroup meeting for LDS traffic only.  __syncthreads() is a workgroup-scope FENCE and a barrier: the fence waits for
+// every global store of the wave (s_waitcnt vmcnt(0)) — 0.5-1 us behind a handful of write-through stores, i.e. exactly
+// the drain k_block_chain2 keeps off its critical path.  Here only the wave's LDS operations are waited for.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// workgroup-wide; result valid in every thread.  `sh` needs blockDim.x / 64 entries.
+__device__ __forceinline__ RatioRow rr_block_min2(RatioRow x, RatioRow* sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  x = rr_wave_min_all(x);
+  lds_barrier();
+  if (lane == 0) sh[wave] = x;
+  lds_barrier();
+  RatioRow r = sh[0];
+  for (int w = 1; w < nw; ++w) r = rr_min(r, sh[w]);
+  return r;
+}
+
 constexpr int kChain2Threads = 256;
 template <int KB, int NT>
 __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   static_assert(KB == 32 || KB == 64, "ring half of 32 or 64 slots");
   static_assert(NT % 64 == 0 && NT >= 256 && NT >= 2 * KB + 64, "lanes for the pending pivots and the loader lane");
+  constexpr int NC = 2 * KB / 8;   // chunks of eight pending pivots: [0, KB / 8) the previous block's, then this block's
   __shared__ RatioRow sh_rr[NT / 64];
   __shared__ unsigned long long sh_mask[2];
   __shared__ unsigned sh_part[kChainMaxWgs * 8], sh_hand[8];
-  __shared__ double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB], sh_win[2];
-  __shared__ int sh_e[2 * KB], sh_l[2 * KB];
+  __shared__ __attribute__((aligned(16))) double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB];
+  __shared__ __attribute__((aligned(16))) int sh_e[2 * KB], sh_l[2 * KB];
+  __shared__ double sh_win[2];
   __shared__ int sh_fail;
+#ifdef LPX_CHAIN2_FINE   // diagnostic build: 16 stamps per decision (slots 8..15: inside the phases)
+#define LPX_C2_STAMP(k) if (P.dbg && lead) P.dbg[s * 16 + (k)] = wall_clock64();
+#define LPX_C2_STRIDE 16
+#else
+#define LPX_C2_STAMP(k)
+#define LPX_C2_STRIDE 8
+#endif
   const double* __restrict__ A = P.A;
   const double* __restrict__ b = P.b;
   const int64_t ld = P.ld, mp = P.mp;
   const int n = P.n, m = P.m, nb = P.nb, n_old = P.n_old;
   LpxCtl* const ctl = P.ctl;
   const int G = gridDim.x, T = G * NT, tid = threadIdx.x, gid = blockIdx.x * NT + tid;
-  const bool lead = gid == 0;
-  constexpr int row0 = 0;   // one device: local row = global row
+  const bool lead = gid == 0;                                   // stamps, the next launch's barrier counter
+  const bool book = blockIdx.x == (unsigned)(G - 1) && tid == 0;   // keeps the loop state (off workgroup 0's path)
   if (tid == 0) {
     sh_fail = 0;
     if (P.census) P.census[blockIdx.x] = xcc_id() + 1u;
@@ -1620,10 +1680,21 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   if (lead) st_agent(reinterpret_cast<int32_t*>(P.bar_next), 0);
   int e = ctl->e_next;
   if (ctl->status != kRunning || e < 0 || nb < 1) {
-    if (lead && nb >= 1) P.up[0].do_update = 0;
-    if (lead) chain_publish(ctl, P.host_snap);
+    if (book && nb >= 1) P.up[0].do_update = 0;
+    if (book) chain_publish(ctl, P.host_snap);
     return;
   }
+  // Identity padding instead of per-step predicates.  Inside a chunk of eight pending pivots every step runs without a
+  // test; a step that is not (yet) a pivot must leave the value alone for every input, -0.0 included: multiplier +0 and
+  // row / column value +0 (x - (+0 * +0) = x, fma(-(+0), +0, x) = x), entering slot / leaving row -1 (matches nothing).
+  // The LDS parameters of such steps hold these from here on, and the thread zeroes its own copies of THIS block's ring
+  // half (slot s is filled at decision s); the previous block's half keeps the zeros behind its last pivot.
+  // (Per-step uniform predicates cost ~130 SGPR masks, spilled through v_writelane / v_readlane at every decision.)
+  if (tid < 2 * KB) {
+    sh_pe[tid] = 0.0; sh_cs[tid] = 0.0; sh_dv[tid] = 0.0; sh_p[tid] = 1.0; sh_bl[tid] = 0.0;
+    sh_e[tid] = -1; sh_l[tid] = -1;
+  }
+  lds_barrier();
   if (tid < n_old) {
     const LpxCtl& q = P.up_o[tid];
     sh_e[tid] = q.e_cur; sh_l[tid] = q.l; sh_p[tid] = q.p; sh_bl[tid] = q.bl;
@@ -1645,11 +1716,19 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   const uint32_t mp8_0 = (uint32_t)mp * 8u, ld8_0 = (uint32_t)ld * 8u;   // (launcher: 64 * max(mp, ld) * 8 < 2^32)
   bool have_rec = false;   // sh_hand[1..4] hold c[e] and prow_{s-1}[e] of the record that named e (uniform)
   unsigned long long* const hand = P.hand;
-  __syncthreads();
+  for (int i = gid; i < m; i += T) {     // this block's half of the thread's own column copies: +0 until a decision fills a slot
+#pragma unroll 8
+    for (int u = 0; u < KB; ++u) P.own_col[(int64_t)u * mp + i] = 0.0;
+  }
+  for (int j = jfirst; j < (int)ld; j += jstep) {
+#pragma unroll 8
+    for (int u = 0; u < KB; ++u) P.own_prow[(int64_t)u * ld + j] = 0.0;
+  }
+  lds_barrier();
 
   for (int s = 0; s < nb; ++s) {
     // ------------------------------------------------------------------ phase A: column e, ratio test
-    if (P.dbg && lead) P.dbg[s * 5 + 0] = wall_clock64();
+    if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 0] = wall_clock64();
     // the ring pitches, made opaque per decision: otherwise the 128 slot offsets of the ring loads are hoisted out of the
     // decision loop as loop invariants and live (spilled) across it
     uint32_t mp8 = mp8_0, ld8 = ld8_0;
@@ -1661,11 +1740,14 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       const unsigned long long mask = __ballot(valid_mine && sh_e[tid] == e);
       if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
     }
-    __syncthreads();
+    lds_barrier();
     const int ra = chain_restart<KB>(sh_mask);
     const int fo_a = ra < 0 ? 0 : (ra < KB ? ra + 1 : n_old);
     const int fn_a = ra >= KB ? ra - KB + 1 : 0;
     const bool use_b = P.b_from_tableau && s == 0;
+    // chunk c of the pending pivots: live / entirely live range tests (uniform)
+    auto first_a = [&](int c) { return c < KB / 8 ? fo_a : fn_a; };
+    auto last_of = [&](int c) { return c < KB / 8 ? n_old : s; };
     // every load of the phase in ONE round trip; the lanes of the pending pivots first
     double pe_mine = 0.0, pc_mine = 0.0;
     const bool pe_from_rec = have_rec && tid == KB + s - 1;   // (s >= 1 whenever have_rec)
@@ -1673,44 +1755,82 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     if (tid == NT - 1 && !have_rec) pc_mine = ld_agent(&P.c[e]);
     RatioRow best = rr_none();
     double best_a = 0.0, best_b = 0.0;
-    double a = 0.0, bi = 0.0;
-    double cs[KB], cso[KB];   // this thread's own stores, only the chunks with a live step
+    double a = 0.0, bi = 0.0, a_first = 0.0, b_first = 0.0;
+    double cv[2 * KB];   // this thread's own stores, only the chunks with a live step
     auto load_row = [&](int i) {
-      const double* src_a = ra < 0 ? &A[(int64_t)i * ld + e]
-                                   : (ra < KB ? &P.own_dvc_o[(int64_t)ra * mp + i] : &P.own_dvc[(int64_t)(ra - KB) * mp + i]);
-      a = *src_a;
-      bi = use_b ? b[i] : P.own_b[i];
       const uint32_t i8 = (uint32_t)i * 8u;   // uniform base (SGPRs) + one 32-bit lane offset per load: the rings are < 4 GiB
+      // a pending pivot entered at the same slot: the column restarts from what that pivot left there, -(col / p)
+      // (1 / p in its own row), computed from the thread's copy of the column as it was BEFORE that pivot
+      a = ra < 0 ? ((P.diag & 1) ? A[(int64_t)(e & 7) * ld + i] : A[(int64_t)i * ld + e])
+                 : *reinterpret_cast<const double*>((ra < KB ? oc_o : oc_n) + ((uint32_t)(ra & (KB - 1)) * mp8 + i8));
+      bi = use_b ? b[i] : P.own_b[i];
 #pragma unroll
-      for (int r0 = 0; r0 < KB; r0 += 8)
-        if (LPX_CHAIN_LIVE(r0, fo_a, n_old)) {
+      for (int c = 0; c < NC; ++c) {
+        const int r0 = (c * 8) & (KB - 1);
+        if (r0 < last_of(c) && r0 + 8 > first_a(c)) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) cso[r0 + q] = *reinterpret_cast<const double*>(oc_o + ((uint32_t)(r0 + q) * mp8 + i8));
+          for (int q = 0; q < 8; ++q)
+            cv[c * 8 + q] = *reinterpret_cast<const double*>((c < KB / 8 ? oc_o : oc_n) + ((uint32_t)(r0 + q) * mp8 + i8));
         }
-#pragma unroll
-      for (int r0 = 0; r0 < KB; r0 += 8)
-        if (LPX_CHAIN_LIVE(r0, fn_a, s)) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q) cs[r0 + q] = *reinterpret_cast<const double*>(oc_n + ((uint32_t)(r0 + q) * mp8 + i8));
-        }
+      }
     };
     int i = gid;
     if (i < m) load_row(i);
     // everything has been asked for; by the time it is here, whatever this wave stored during the previous decision has
     // long landed: the drain that makes those stores visible before this workgroup publishes anything newer is free
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 1] = wall_clock64();   // this wave's loads of phase A are here
     if (valid_mine) sh_pe[tid] = pe_from_rec ? from32(sh_hand[3], sh_hand[4]) : pe_mine;
     if (tid == NT - 1 && !have_rec) { sh_hand[1] = lo32(pc_mine); sh_hand[2] = hi32(pc_mine); }
-    __syncthreads();
+    lds_barrier();
+    LPX_C2_STAMP(8)
     while (i < m) {
-      const int ig = row0 + i;
+      const int ig = i;
+      if (ra >= 0) {   // (uniform, rare) the restart value
+        const double p_r = sh_p[ra];
+        a = (ig == sh_l[ra]) ? __ddiv_rn(1.0, p_r) : -__ddiv_rn(a, p_r);              // :139 / :157
+      }
+      // the pending pivots in order; their parameters one chunk ahead of the arithmetic, 16-byte LDS reads
+      double pe8[2][8];
+      int l8[2][8];
+      auto params = [&](int c) {
+        const int r0 = (c * 8) & (KB - 1);
+        if (c < NC && r0 < last_of(c) && r0 + 8 > first_a(c)) {
 #pragma unroll
-      for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_A(0, r0, fo_a, n_old, cso)
-      P.col0[(int64_t)s * mp + i] = a;   // the entry the sweep of THIS block will read (for the fix-up: next kernel)
+          for (int q = 0; q < 8; ++q) { pe8[c & 1][q] = sh_pe[c * 8 + q]; l8[c & 1][q] = sh_l[c * 8 + q]; }
+        }
+      };
+      params(0);
 #pragma unroll
-      for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_A(KB, r0, fn_a, s, cs)
+      for (int c = 0; c < NC; ++c) {
+        params(c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == KB / 8) P.col0[(int64_t)s * mp + i] = a;   // the entry the sweep of THIS block will read (fix-up: next kernel)
+        const int r0 = (c * 8) & (KB - 1), first = first_a(c), last = last_of(c);
+        if (r0 < last && r0 + 8 > first) {
+          if (first <= r0) {   // eight steps, no predicate: what lies behind the last pivot is identity by its data
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const double t_ = submul(a, cv[c * 8 + q], pe8[c & 1][q]);
+              a = (ig == l8[c & 1][q]) ? pe8[c & 1][q] : t_;
+            }
+          } else {             // (rare) a restart inside this chunk: its steps one by one, the ring value fetched again
+            const char* const oc = c < KB / 8 ? oc_o : oc_n;
+#pragma unroll 1
+            for (int u = first; u < min(last, r0 + 8); ++u) {
+              const double csu = *reinterpret_cast<const double*>(oc + ((uint32_t)u * mp8 + (uint32_t)i * 8u));
+              const double peu = sh_pe[(c < KB / 8 ? 0 : KB) + u];
+              const double t_ = submul(a, csu, peu);
+              a = (ig == sh_l[(c < KB / 8 ? 0 : KB) + u]) ? peu : t_;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      LPX_C2_STAMP(9)
       st_agent(&P.col[(int64_t)s * mp + i], a);
       P.own_col[(int64_t)s * mp + i] = a;
+      if (i == gid) { a_first = a; b_first = bi; }   // (kept for the b update behind phase B: no reload)
       const double rt = ratio_of(a, bi);
       if (rt < best.ratio) {  // i ascends per thread: strict < keeps the lowest row among equal ratios
         best = RatioRow{rt, ig, 0};
@@ -1721,16 +1841,18 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       __builtin_amdgcn_sched_barrier(0);   // (the next pass's loads stay behind this pass's arithmetic: one set of registers)
       if (i < m) load_row(i);   // (tableaus taller than the grid: a round trip per further row)
     }
+    LPX_C2_STAMP(10)
     const double pc = from32(sh_hand[1], sh_hand[2]);   // c[e]: from the record that named e, or the loader lane
     const unsigned xtag = P.hand_base + (unsigned)s;    // sequence number of this decision (unique over launches)
     {
-      const RatioRow w = rr_block_min(best, sh_rr);
+      const RatioRow w = rr_block_min2(best, sh_rr);
+      LPX_C2_STAMP(11)
       if (w.row != INT_MAX && best.row == w.row) { sh_win[0] = best_a; sh_win[1] = best_b; }
-      __syncthreads();
+      lds_barrier();
       const double wa = (w.row != INT_MAX) ? sh_win[0] : 0.0, wb = (w.row != INT_MAX) ? sh_win[1] : 0.0;
-      if (P.dbg && lead) P.dbg[s * 5 + 1] = wall_clock64();
+      if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 2] = wall_clock64();
       // the workgroup's candidate as seven tagged granules — NOT behind a drain: nobody reads col_s across workgroups
-      // before decision s + 1, and every wave has passed a vmcnt(0) (the meeting above) since its stores of decision s - 1
+      // before decision s + 1, and every wave has passed a vmcnt(0) (above) since its stores of decision s - 1
       unsigned long long* const gran = reinterpret_cast<unsigned long long*>(P.partA) + (size_t)(s & 1) * kChainMaxWgs * 8;
       if (tid < 7) {
         const unsigned d = tid == 0 ? lo32(w.ratio) : tid == 1 ? hi32(w.ratio) : tid == 2 ? lo32(wa) : tid == 3 ? hi32(wa)
@@ -1749,13 +1871,13 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
         sh_part[idx] = (unsigned)g;
       }
       if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __syncthreads();
+      lds_barrier();
       if (sh_fail) {
-        if (lead) { ctl->status = 7 /* LPX_DEVICE_ERROR */; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); }
+        if (book) { ctl->status = 7 /* LPX_DEVICE_ERROR */; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); }
         return;
       }
     }
-    if (P.dbg && lead) P.dbg[s * 5 + 2] = wall_clock64();
+    if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 3] = wall_clock64();
 
     // ------------------------------------------------------------------ phase B: the leaving row
     RatioRow mine = rr_none();
@@ -1767,37 +1889,39 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       mine_b = from32(q[4], q[5]);
       mine.row = (int)q[6];
     }
-    const RatioRow w = rr_block_min(mine, sh_rr);
+    const RatioRow w = rr_block_min2(mine, sh_rr);
     if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
-    __syncthreads();
+    lds_barrier();
     if (w.row == INT_MAX || !(w.ratio < kInf)) {  // getLeaving() == -1: unbounded
-      if (lead) {
+      if (book) {
         ctl->status = 1; ctl->do_update = 0; ctl->l = -1; ctl->ratio = w.ratio; P.up[s].do_update = 0;
         chain_publish(ctl, P.host_snap);
       }
       return;
     }
     if (max_pivots >= 0 && pivots >= max_pivots) {
-      if (lead) {
+      if (book) {
         ctl->status = 9 /* LPX_PIVOT_LIMIT */; ctl->do_update = 0; P.up[s].do_update = 0;
         chain_publish(ctl, P.host_snap);
       }
       return;
     }
+    LPX_C2_STAMP(12)
     const int l = w.row;
     const double p = sh_win[0], raw_b = sh_win[1];
     if (p == 0.0) {  // ArithmeticException in the reference, LPState.java:139
-      if (lead) { ctl->status = 8; ctl->do_update = 0; P.up[s].do_update = 0; chain_publish(ctl, P.host_snap); }
+      if (book) { ctl->status = 8; ctl->do_update = 0; P.up[s].do_update = 0; chain_publish(ctl, P.host_snap); }
       return;
     }
     if (tid < 2 * KB) {   // restart pivot of row l: LDS only
       const unsigned long long mask = __ballot(valid_mine && sh_l[tid] == l);
       if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
     }
-    __syncthreads();
+    lds_barrier();
     const int rb = chain_restart<KB>(sh_mask);
     const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
     const int fn_b = rb >= KB ? rb - KB + 1 : 0;
+    auto first_b = [&](int c) { return c < KB / 8 ? fo_b : fn_b; };
     // again everything in one round trip: col_u[l] of the pending pivots first, then the thread's column of row l
     double cs_mine = 0.0;
     if (valid_mine) cs_mine = ld_agent((old_mine ? P.col_o : P.col) + (int64_t)r_mine * mp + l);
@@ -1807,45 +1931,76 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     double rec_c = 0.0, rec_pr = 0.0;   // workgroup 0: what its thread of slot j would put into the hand-off record
     const double* rowl = A + (int64_t)l * ld;
     double x = 0.0, cj = 0.0;
-    double prv[KB], prvo[KB];   // this thread's own stores, live chunks only
     auto load_col = [&](int j) {
       cj = ld_agent(&P.c[j]);  // this thread's own store (or the initial value)
       x = 0.0;
       if (j < n) {
-        const double* src_x = rb < 0 ? &rowl[j]
-                                     : (rb < KB ? &P.own_prow_o[(int64_t)rb * ld + j] : &P.own_prow[(int64_t)(rb - KB) * ld + j]);
-        x = *src_x;
         const uint32_t j8 = (uint32_t)j * 8u;
+        x = rb < 0 ? rowl[j]
+                   : *reinterpret_cast<const double*>((rb < KB ? op_o : op_n) + ((uint32_t)(rb & (KB - 1)) * ld8 + j8));
 #pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8)
-          if (LPX_CHAIN_LIVE(r0, fo_b, n_old)) {
+        for (int c = 0; c < NC; ++c) {
+          const int r0 = (c * 8) & (KB - 1);
+          if (r0 < last_of(c) && r0 + 8 > first_b(c)) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) prvo[r0 + q] = *reinterpret_cast<const double*>(op_o + ((uint32_t)(r0 + q) * ld8 + j8));
+            for (int q = 0; q < 8; ++q)
+              cv[c * 8 + q] = *reinterpret_cast<const double*>((c < KB / 8 ? op_o : op_n) + ((uint32_t)(r0 + q) * ld8 + j8));
           }
-#pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8)
-          if (LPX_CHAIN_LIVE(r0, fn_b, s)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) prv[r0 + q] = *reinterpret_cast<const double*>(op_n + ((uint32_t)(r0 + q) * ld8 + j8));
-          }
+        }
       }
     };
     int j = jfirst;
     if (j < (int)ld) load_col(j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as in phase A: also the free drain of this wave's earlier stores)
+    if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 4] = wall_clock64();   // this wave's loads of phase B are here
     if (valid_mine) {
       sh_cs[tid] = cs_mine;
       sh_dv[tid] = -__ddiv_rn(cs_mine, sh_p[tid]);
     }
-    __syncthreads();
+    lds_barrier();
+    LPX_C2_STAMP(13)
     while (j < (int)ld) {
       if (j < n) {
+        double cs8[2][8], dv8[2][8];
+        int e8[2][8];
+        auto params = [&](int c) {
+          const int r0 = (c * 8) & (KB - 1);
+          if (c < NC && r0 < last_of(c) && r0 + 8 > first_b(c)) {
 #pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(0, r0, fo_b, n_old, prvo)
-        P.row0[(int64_t)s * ld + j] = x;   // the row as the sweep of this block will read it (for the fix-up: next kernel)
+            for (int q = 0; q < 8; ++q) {
+              cs8[c & 1][q] = sh_cs[c * 8 + q]; dv8[c & 1][q] = sh_dv[c * 8 + q]; e8[c & 1][q] = sh_e[c * 8 + q];
+            }
+          }
+        };
+        params(0);
 #pragma unroll
-        for (int r0 = 0; r0 < KB; r0 += 8) LPX_CHAIN_CHUNK_B(KB, r0, fn_b, s, prv)
+        for (int c = 0; c < NC; ++c) {
+          params(c + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (c == KB / 8) P.row0[(int64_t)s * ld + j] = x;   // the row as the sweep of this block will read it (fix-up)
+          const int r0 = (c * 8) & (KB - 1), first = first_b(c), last = last_of(c);
+          if (r0 < last && r0 + 8 > first) {
+            if (first <= r0) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const double t_ = submul(x, cs8[c & 1][q], cv[c * 8 + q]);
+                x = (j == e8[c & 1][q]) ? dv8[c & 1][q] : t_;
+              }
+            } else {           // (rare) a restart inside this chunk
+              const char* const op = c < KB / 8 ? op_o : op_n;
+#pragma unroll 1
+              for (int u = first; u < min(last, r0 + 8); ++u) {
+                const double pru = *reinterpret_cast<const double*>(op + ((uint32_t)u * ld8 + (uint32_t)j * 8u));
+                const int k = (c < KB / 8 ? 0 : KB) + u;
+                const double t_ = submul(x, sh_cs[k], pru);
+                x = (j == sh_e[k]) ? sh_dv[k] : t_;
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
+      LPX_C2_STAMP(14)
       double cn, pr;
       if (j == e) {
         pr = inv_p;
@@ -1867,12 +2022,13 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       __builtin_amdgcn_sched_barrier(0);
       if (j < (int)ld) load_col(j);
     }
+    LPX_C2_STAMP(15)
     if (window && blockIdx.x == 0) {
       // Workgroup 0 has finished slots 0..255.  Under the first-positive rule the next entering slot is the lowest one
       // with c > eps: if there is one among them it is the answer, and the thread that owns it publishes {slot, c[slot],
       // prow_s[slot]} — all the next phase A needs of this decision — as five tagged granules, no drain.  No candidate
       // here: "none", and everybody takes the grid barrier below.
-      const RatioRow w0 = rr_block_min(cand, sh_rr);
+      const RatioRow w0 = rr_block_min2(cand, sh_rr);
       const unsigned long long tg = (unsigned long long)xtag << 32;
       if (w0.row == INT_MAX ? tid == 0 : tid == w0.row) {
         const bool none = w0.row == INT_MAX;
@@ -1883,23 +2039,17 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
         __hip_atomic_store(&hand[0], tg | (unsigned)((none ? -2 : w0.row) + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    // the row owners add pivot s to their two running columns: the entering column after the pivot (what a later
-    // decision restarts from) and b — after the columns, so that workgroup 0 publishes the entering slot first
-    for (int i = gid; i < m; i += T) {
-      const double colv = P.own_col[(int64_t)s * mp + i];
-      const double bcur = use_b ? b[i] : P.own_b[i];
-      P.own_dvc[(int64_t)s * mp + i] = (row0 + i == l) ? inv_p : -__ddiv_rn(colv, p);    // :157 / :139
-      P.own_b[i] = (row0 + i == l) ? bl : submul(bcur, colv, bl);                        // :146 / :164
+    if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 5] = wall_clock64();   // workgroup 0: the hand-off record is on its way
+    // the row owners add pivot s to b (kept with every decided pivot applied) — after the columns, so that workgroup 0
+    // publishes the entering slot first
+    if (gid < m) P.own_b[gid] = (gid == l) ? bl : submul(b_first, a_first, bl);      // :146 / :164
+    for (int i2 = gid + T; i2 < m; i2 += T) {
+      const double colv = P.own_col[(int64_t)s * mp + i2];
+      const double bcur = use_b ? b[i2] : P.own_b[i2];
+      P.own_b[i2] = (i2 == l) ? bl : submul(bcur, colv, bl);
     }
-    {
-      const RatioRow w2 = rr_block_min(cand, sh_rr);
-      if (tid == 0) {
-        st_agent(&P.partB[blockIdx.x].ratio, w2.ratio);
-        st_agent(&P.partB[blockIdx.x].row, w2.row);
-        sh_e[KB + s] = e; sh_l[KB + s] = l; sh_p[KB + s] = p; sh_bl[KB + s] = bl;
-      }
-    }
-    if (lead) {
+    if (tid == 0) { sh_e[KB + s] = e; sh_l[KB + s] = l; sh_p[KB + s] = p; sh_bl[KB + s] = bl; }
+    if (book) {
       v = addmul(v, bl, pc);                                                       // :171
       const int32_t perm_e = P.perm[e], perm_l = P.perm[n + l];                    // exchangeIndexes :311-320
       P.perm[e] = perm_l;
@@ -1911,7 +2061,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       LpxCtl& up = P.up[s];
       up.p = p; up.bl = bl; up.e_cur = e; up.l = l; up.e_next = -1; up.parity = 0; up.do_update = 1;
     }
-    if (P.dbg && lead) P.dbg[s * 5 + 3] = wall_clock64();
+    if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 6] = wall_clock64();
     int e_next = -2;
     have_rec = false;
     if (window) {  // five lanes per workgroup wait for workgroup 0's record (bounded, like the barrier)
@@ -1926,26 +2076,31 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
         }
         sh_hand[tid] = (unsigned)rec;
       }
-      __syncthreads();
-      if (sh_fail) { if (lead) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
+      lds_barrier();
+      if (sh_fail) { if (book) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
       e_next = (int)sh_hand[0] - 2;
       have_rec = e_next >= 0;
     }
     if (e_next < 0) {  // no hand-off (Dantzig, narrow tableau) or no candidate in its window: the full exchange
+      const RatioRow w2 = rr_block_min2(cand, sh_rr);
+      if (tid == 0) {
+        st_agent(&P.partB[blockIdx.x].ratio, w2.ratio);
+        st_agent(&P.partB[blockIdx.x].row, w2.row);
+      }
       target += (unsigned)G;
       if (!grid_barrier(P.bar, target, &sh_fail, P.fences, P.spin_max)) {
-        if (lead) { ctl->status = 7; chain_publish(ctl, P.host_snap); }
+        if (book) { ctl->status = 7; chain_publish(ctl, P.host_snap); }
         return;
       }
       RatioRow m2 = rr_none();
       if (tid < G) { m2.ratio = ld_agent(&P.partB[tid].ratio); m2.row = ld_agent(&P.partB[tid].row); }
-      const RatioRow w3 = rr_block_min(m2, sh_rr);
+      const RatioRow w3 = rr_block_min2(m2, sh_rr);
       e_next = (w3.row == INT_MAX) ? -1 : w3.row;
     }
-    if (P.dbg && lead) P.dbg[s * 5 + 4] = wall_clock64();
+    if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 7] = wall_clock64();
     pivots += 1;
     parity ^= 1;
-    if (lead) {
+    if (book) {
       ctl->v = v; ctl->p = p; ctl->bl = bl; ctl->pc = pc; ctl->ratio = w.ratio;
       ctl->e_cur = e; ctl->l = l; ctl->e_next = e_next; ctl->parity = parity; ctl->pivots = pivots;
       ctl->track = track; ctl->do_update = 1;
@@ -1955,13 +2110,15 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       }
     }
     if (e_next < 0 || s + 1 == nb) {
-      if (lead) chain_publish(ctl, P.host_snap);
+      if (book) chain_publish(ctl, P.host_snap);
       return;
     }
     e = e_next;
-    __syncthreads();   // sh_e[KB + s] .. and sh_hand are read by the next decision; sh_mask / sh_win are rewritten
+    lds_barrier();   // sh_e[KB + s] .. and sh_hand are read by the next decision; sh_mask / sh_win are rewritten
   }
 }
+#undef LPX_C2_STAMP
+#undef LPX_C2_STRIDE
 #undef LPX_CHAIN_STEP_A
 #undef LPX_CHAIN_STEP_B
 #undef LPX_CHAIN_CHUNK_A
@@ -3681,6 +3838,8 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
   P.hand_base = (unsigned)(seq + 1) * 64u;  // > any sequence of earlier launches (<= kBlockMax decisions each)
   P.dantzig = dantzig; P.fences = fences; P.host_snap = host_snap; P.dbg = trace ? R.chain_dbg : nullptr;
   P.spin_max = (mg && mg->spin_max) ? mg->spin_max : (1u << 22);
+  static const int chain_diag = getenv("LPX_CHAIN_DIAG") ? atoi(getenv("LPX_CHAIN_DIAG")) : 0;   // timing experiments only
+  P.diag = chain_diag;
   P.census = R.census;
   if (mg) {
     P.shard_row0 = mg->row0; P.m_global = mg->m_global; P.n_dev = mg->n_dev; P.dev = mg->dev;

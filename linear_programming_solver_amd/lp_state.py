@@ -185,6 +185,17 @@ class LPState:
             raise_for_status(rc)
         return buf[: 5 * nd.value].reshape(nd.value, 5)
 
+    def chain_trace_fine(self):
+        """Every stamp the decision kernel keeps: array [decisions, 8] for k_block_chain2 (option chain_form = 1: start,
+        phase A's loads arrived, candidate published, every candidate read, phase B's loads arrived, hand-off stored,
+        phase B done, next entering slot known), [decisions, 5] otherwise."""
+        buf = np.zeros(16 * 64, dtype=np.int64)
+        nd, ns = C.c_int32(), C.c_int32()
+        rc = self._L.lpx_state_read_chain_trace_fine(self._h, buf.ctypes.data_as(_lib.i64p), 64, C.byref(nd), C.byref(ns))
+        if rc:
+            raise_for_status(rc)
+        return buf[: ns.value * nd.value].reshape(nd.value, ns.value)
+
     def block(self):
         """Pivots per sweep in effect for the device loop (1 = one update pass per pivot)."""
         return int(self._L.lpx_state_get_block(self._h))
