@@ -3346,6 +3346,327 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_pull(double* __restrict__ A,
   dma_wait<0>();   // stage 1's pending ticket atomics write registers of this wave: let them land before it ends
 }
 
+// ---- blocks of 33..64 pivots by ONE wave per sub-strip (round 4) -----------------------------------------------------
+// k_sweep64_pull needs a PAIR of waves per 128-column sub-strip because 64 pivot-row slices of two doubles do not fit one
+// wave.  They do when the sub-strip is 64 columns wide: a lane owns ONE column and keeps its 64 pivot-row values in 128
+// VGPRs.  Then the worker is a single wave again and the loop is k_sweep32_pull's, nothing handed over, no second wave
+// to wait for: tickets per sub-strip, LDS-DMA staging, hand-counted vmcnt.  What changes with the width:
+//   * a batch is 4 rows x 512 bytes; one LDS-DMA instruction (64 lanes x 16 bytes) brings TWO rows — lanes 0..31 the
+//     first, lanes 32..63 the second (per-lane offsets) — so a batch is two of them, landing as four contiguous rows;
+//   * the batch's multipliers ([pivot][row], 64 x 4 doubles = 2 KiB, the layout k_pack_multipliers<64> writes) are two
+//     LDS-DMA instructions; per step the wave reads its four multipliers as two 16-byte broadcasts;
+//   * a lane reads and stores 8 bytes per row (ds_read_b64, global_store_dwordx2).
+// Per iteration: 2 + 2 LDS-DMAs, 1 ticket atomic, 4 stores = 9 operations; behind the atomic of iteration i - 3 come its
+// 4 stores and 2 x 9: vmcnt(22).  With fused arithmetic the 64 steps are 256 v_fma_f64 per batch and wave — the sweep's
+// instruction floor at cfg4 is 1.2 ms at 2 GHz against a memory pass of ~1.45 ms for HALF the bytes per pivot of a
+// block of 32.  Blocks with fewer than 33 valid pivots, the partial last strip and tableaus whose height is not a
+// multiple of 4 are left to the generic kernels, as with k_sweep64_pull.
+constexpr int kOneSlotBytes = kDmaRB * 512;                                  // a batch: 4 rows x 64 columns
+constexpr int kOneWaveBytes = kPullNS * kOneSlotBytes + kPullNM * 2048;      // 14 KiB per wave
+static_assert(8 * kOneWaveBytes <= 160 * 1024, "two workgroups per CU");
+
+// (the instruction offset of an LDS-DMA load moves BOTH addresses: the second KiB of the multipliers needs no M0 step)
+template <bool NT>
+__device__ __forceinline__ void dma_batch2m2(const char* base, uint32_t o0, uint32_t o1, uint32_t lds, const char* mbase,
+                                             uint32_t om, uint32_t lds_m) {
+  unsigned keep;
+  if (NT)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %1 nt\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %6, %5\n\t"
+                 "global_load_lds_dwordx4 %6, %5 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "s"(lds), "s"(mbase), "v"(om), "s"(lds_m)
+                 : "memory", "scc");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %1\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %6, %5\n\t"
+                 "global_load_lds_dwordx4 %6, %5 offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "s"(lds), "s"(mbase), "v"(om), "s"(lds_m)
+                 : "memory", "scc");
+}
+
+// 64 steps on a batch of 4 rows x one column per lane; multipliers [pivot][4 rows] in LDS, read two steps ahead
+template <int K>
+__device__ __forceinline__ void sweep_apply_one(double (&x)[4], const double (&pr)[K], const double* mrow) {
+  constexpr int D = 2;
+  d2 cc[D + 1][2];
+#pragma unroll
+  for (int s = 0; s < D && s < K; ++s) {
+    cc[s][0] = *reinterpret_cast<const d2*>(mrow + s * 4);
+    cc[s][1] = *reinterpret_cast<const d2*>(mrow + s * 4 + 2);
+  }
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    if (s + D < K) {
+      cc[(s + D) % (D + 1)][0] = *reinterpret_cast<const d2*>(mrow + (s + D) * 4);
+      cc[(s + D) % (D + 1)][1] = *reinterpret_cast<const d2*>(mrow + (s + D) * 4 + 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const d2 c01 = cc[s % (D + 1)][0], c23 = cc[s % (D + 1)][1];
+    x[0] = submul(x[0], c01.x, pr[s]);                                             // LPState.java:162
+    x[1] = submul(x[1], c01.y, pr[s]);
+    x[2] = submul(x[2], c23.x, pr[s]);
+    x[3] = submul(x[3], c23.y, pr[s]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <bool NT, bool OOP>
+__global__ __launch_bounds__(256, 2) void k_sweep64_one(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                        int64_t ld, int m_local,
+                                                        const double* __restrict__ prow_ring,
+                                                        const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
+                                                        const double* __restrict__ col_packed,   // [batch][64][4]
+                                                        unsigned* __restrict__ tickets) {
+  constexpr int K = 64, RB = kDmaRB, NS = kPullNS, NM = kPullNM;
+  constexpr int kOps = 2 + 2 + 1 + RB;             // per iteration: 2 row DMAs, 2 multiplier DMAs, 1 atomic, RB stores
+  constexpr int kAhead = RB + (NS - 1) * kOps;     // younger than the atomic of iteration i - NS at iteration i's wait
+  static_assert(kAhead <= 60 && RB == 4, "vmcnt is six bits wide; a batch is two two-row DMAs");
+  __shared__ __attribute__((aligned(16))) char sm[4 * kOneWaveBytes];
+  const int np = ring_count(ring, K, kmax, reinterpret_cast<int*>(sm));
+  __syncthreads();   // everyone has read the count before a DMA lands on it
+  if (np <= 32) return;   // 0..32 pivots: the generic kernels behind this launch take the block (two passes)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // the grid is G workgroups per group of four sub-strips (256 columns); XCD x walks the groups shifted by
+  // x * ngroups / 8 (see k_sweep32_pull)
+  const int ngroups = nstrips_full * 2;
+  const int grp = (ngroups % 8 == 0)
+                      ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(ngroups / 8)) % (unsigned)ngroups)
+                      : (int)(blockIdx.x % (unsigned)ngroups);
+  const int sub = grp * 4 + wave;                  // 64-column sub-strip
+  const int nbt = m_local / RB;                    // batches of the tableau (m_local % RB == 0: launcher)
+  unsigned* const ctr = tickets + sub * 32;        // one counter per sub-strip, 128 bytes apart
+  const int64_t row_bytes = ld * 8;
+  const int64_t batch_bytes = RB * row_bytes;
+  char* const dst_base = reinterpret_cast<char*>(A + sub * 64);
+  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + sub * 64) : dst_base;
+  const uint32_t rb32 = (uint32_t)row_bytes;       // 3 rows x ld x 8 < 2^32 (launcher)
+  const uint32_t off_r = (uint32_t)(lane >> 5) * rb32 + (uint32_t)(lane & 31) * 16u;   // DMA: two rows per instruction
+  const uint32_t off_m = (uint32_t)lane * 16u;
+  const uint32_t off_x = (uint32_t)lane * 8u;      // the lane's column inside a row of the sub-strip
+  char* const stage = sm + wave * kOneWaveBytes;
+  char* const mult = stage + NS * kOneSlotBytes;
+  const uint32_t lds_stage = lds_addr_of(stage), lds_mult = lds_addr_of(mult);
+  auto issue = [&](int t, int it) {   // batch t becomes iteration it's: rows -> stage slot it % NS, multipliers -> it % NM
+    const char* const base = src_base + (int64_t)t * batch_bytes;                                     // uniform
+    const char* const mbase = reinterpret_cast<const char*>(col_packed) + (int64_t)t * 2048;          // uniform
+    dma_batch2m2<NT>(base, off_r, off_r + 2 * rb32,
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_stage + (uint32_t)((it % NS) * kOneSlotBytes))),
+                     mbase, off_m, (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_mult + (uint32_t)((it % NM) * 2048))));
+  };
+
+  // prologue: tickets of iterations 0 .. NS-1, their DMAs, the tickets of iterations NS .. 2 NS - 1 (pending), the
+  // lane's 64 pivot-row values; everything is waited for
+  unsigned tk[NS];
+  int bq[NS + 1];   // bq[k]: the batch of iteration i + k (>= nbt: none)
+#pragma unroll
+  for (int u = 0; u < NS; ++u) ticket_pull(tk[u], ctr);
+  dma_wait<0>();
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    bq[u] = ticket_take(tk[u]);
+    if (bq[u] < nbt) issue(bq[u], u);   // uniform
+  }
+#pragma unroll
+  for (int u = 0; u < NS; ++u) ticket_pull(tk[u], ctr);
+  double pr[K];
+#pragma unroll
+  for (int s = 0; s < K; ++s) {
+    pr[s] = prow_ring[(int64_t)s * ld + sub * 64 + lane];
+    if (s >= np) pr[s] = 0.0;   // uniform: identity steps of a partly filled block (multiplier +0 as well)
+  }
+  dma_wait<0>();
+
+  int full = 0;   // consecutive most recent iterations that issued all kOps operations
+#pragma unroll 1
+  for (int i0 = 0;; i0 += NS) {
+    if (bq[0] >= nbt) break;   // tickets only grow: nothing is left for this wave (its pending pulls are waited for below)
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int i = i0 + u;
+      const int t = bq[0];
+      if (t < nbt) {   // uniform
+        // (the first NS iterations need what the prologue issued and waited for)
+        if (full >= NS) dma_wait<kAhead>(); else if (i >= NS) dma_wait<0>();
+        bq[NS] = ticket_take(tk[u]);   // pulled at iteration i - NS: the batch of iteration i + NS
+        const char* const slot = stage + u * kOneSlotBytes + off_x;
+        double x[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) x[r] = *reinterpret_cast<const double*>(slot + r * 512);
+        const bool more = bq[NS] < nbt;
+        if (more) issue(bq[NS], i + NS);   // refills the slot just read (the statement waits for the reads first)
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ticket_pull(tk[u], ctr);
+        full = more ? full + 1 : 0;
+        sweep_apply_one<K>(x, pr, reinterpret_cast<const double*>(mult + (i % NM) * 2048));
+        char* const out = dst_base + (int64_t)t * batch_bytes;   // uniform
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          double* q = reinterpret_cast<double*>(out + (off_x + (uint32_t)r * rb32));
+          if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
+        }
+      } else {
+        bq[NS] = INT_MAX;   // (tickets only grow: what this wave still has pending names nothing either)
+      }
+#pragma unroll
+      for (int k = 0; k < NS; ++k) bq[k] = bq[k + 1];
+    }
+  }
+  dma_wait<0>();   // the pending ticket atomics write registers of this wave: let them land before it ends
+}
+
+// ---- blocks of 33..64 pivots on the matrix cores (round 4; fused-arithmetic mode only) --------------------------------
+// v_mfma_f64_16x16x4_f64 computes D[i][j] = fma(A[i][3], B[3][j], fma(A[i][2], B[2][j], fma(A[i][1], B[1][j],
+// fma(A[i][0], B[0][j], C[i][j])))) — a chain of fused multiply-adds in k order, bit for bit (measured: 512 000 random
+// entries incl. cancellation cases, 0 mismatches; scripts/micro/mfma_f64_order.hip, profiles/r04_mfma_f64_order.txt).
+// That chain IS what the fused mode applies to a tableau entry for four consecutive pending pivots: x <- fma(-col_s[i],
+// prow_s[j], x).  So with A = the negated multipliers (16 rows x 4 pivots), B = the pivot rows (4 pivots x 16 columns)
+// and C = a 16 x 16 tile of the tableau, sixteen MFMAs in pivot order apply a block of 64 to the tile with the bits of 64
+// v_fma_f64 steps.  The rate is the vector unit's (MI355X: fp64 matrix = fp64 vector peak); what the matrix path saves
+// is everything AROUND the arithmetic: one A operand per lane feeds 1024 multiply-adds, where the vector kernels read
+// two 16-byte LDS broadcasts per four (k_sweep64_one is bound by exactly that: LDS issue).
+// A wave is bound to a 64-column sub-strip: its B operands — 16 pivot groups x 4 column tiles, one double per lane —
+// stay in 128 VGPRs.  It pulls 16-row tiles of the sub-strip from the sub-strip's ticket counter; a tile is 16 x 64
+// entries (8 KiB) in the MFMA's C layout (C[4 r + lane / 16][lane % 16] in register r: one global_load_dwordx2 = four
+// 128-byte row segments) plus its 8 KiB of negated multipliers in A layout (k_pack_multipliers_mfma: [tile][group][lane],
+// lane = 16 k + i; -0.0 for the identity steps of a partly filled block, whose B values are +0.0: fma(-0, +0, x) = x).
+// Three tile buffers rotate (ordinary loads, the compiler counts them): while tile t computes its 64 MFMAs, tiles t + 1
+// and t + 2 are in flight.  One wave per SIMD (the register file is the budget), LDS unused.
+#if LPX_FUSED
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+// A operands of the MFMA sweep: colM[(tile * 16 + g) * 64 + 16 k + i] = -col_ring[4 g + k][16 tile + i]
+__global__ __launch_bounds__(256) void k_pack_multipliers_mfma(const double* __restrict__ col_ring, int64_t mp,
+                                                               const LpxCtl* __restrict__ ring, int kmax, int ntiles,
+                                                               double* __restrict__ colM, unsigned* __restrict__ tickets,
+                                                               int nsub, long long* __restrict__ clk) {
+  __shared__ int sh_np;
+  const int np = ring_count(ring, 64, kmax, &sh_np);
+  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime(); clk[1] = wall_clock64(); }
+  if (blockIdx.x == 0)
+    for (int u = threadIdx.x; u < nsub; u += 256) tickets[u * 32] = 0u;
+  // one workgroup per tile: thread = (pivot group pair, lane); reads along rows (i fastest): 128-byte segments
+  const int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * 256 + threadIdx.x;          // 0 .. 1023 = 16 groups x 64 lanes
+    const int g = idx >> 6, l = idx & 63, k = l >> 4, i = l & 15;
+    const int s = 4 * g + k;
+    const double c = s < np ? col_ring[(int64_t)s * mp + (int64_t)tile * 16 + i] : 0.0;
+    colM[(int64_t)tile * 1024 + idx] = -c;
+  }
+}
+
+template <bool NT, bool OOP>
+__global__ __launch_bounds__(256, 1) void k_sweep64_mfma(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                         int64_t ld, int m_local,
+                                                         const double* __restrict__ prow_ring,
+                                                         const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
+                                                         const double* __restrict__ colM,   // [tile][group][lane]
+                                                         unsigned* __restrict__ tickets) {
+  constexpr int NG = 16, CT = 4;   // pivot groups of four, column tiles of sixteen
+  __shared__ int sh_np;
+  const int np = ring_count(ring, 64, kmax, &sh_np);
+  if (np <= 32) return;   // 0..32 pivots: the generic kernels behind this launch take the block (two passes)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ngroups = nstrips_full * 2;
+  const int grp = (ngroups % 8 == 0)
+                      ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(ngroups / 8)) % (unsigned)ngroups)
+                      : (int)(blockIdx.x % (unsigned)ngroups);
+  const int sub = grp * 4 + wave;                  // 64-column sub-strip
+  const int ntiles = m_local / 16;                 // (m_local % 16 == 0: launcher)
+  unsigned* const ctr = tickets + sub * 32;
+  const int64_t row_bytes = ld * 8;
+  char* const dst_base = reinterpret_cast<char*>(A + sub * 64);
+  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + sub * 64) : dst_base;
+  const uint32_t rb32 = (uint32_t)row_bytes;       // 16 rows x ld x 8 < 2^32 (launcher)
+  const uint32_t off_c = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 8u;   // row lane / 16, column lane % 16
+  // B operands: pivot 4 g + lane / 16, column 16 ct + lane % 16 of the sub-strip; +0 for the identity steps
+  double bq[NG][CT];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int s = 4 * g + (lane >> 4);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      bq[g][ct] = s < np ? prow_ring[(int64_t)s * ld + sub * 64 + ct * 16 + (lane & 15)] : 0.0;
+  }
+  // a ticket: the atomic is ISSUED in front of a tile's loads and its value TAKEN behind the arithmetic that follows
+  // (vmcnt counts in order: waiting for the ticket then waits for nothing younger than what the next tile needs anyway)
+  auto pull = [&]() -> unsigned {
+    unsigned t = 0;
+    if (lane == 0) t = atomicAdd(ctr, 1u);
+    return t;
+  };
+  auto take = [&](unsigned raw) -> int { return __builtin_amdgcn_readfirstlane((int)raw); };
+  auto load_tile = [&](int t, d4v (&c)[CT], double (&a)[NG]) {
+    const char* const base = src_base + (int64_t)t * 16 * row_bytes;   // uniform
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const double* q = reinterpret_cast<const double*>(base + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
+        c[ct][r] = NT ? __builtin_nontemporal_load(q) : *q;
+      }
+    const double* const am = colM + (int64_t)t * 1024 + lane;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a[g] = am[g * 64];
+  };
+  auto work_tile = [&](int t, d4v (&c)[CT], const double (&a)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bq[g][ct], c[ct], 0, 0, 0);
+    char* const out = dst_base + (int64_t)t * 16 * row_bytes;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        double* q = reinterpret_cast<double*>(out + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
+        if (NT) __builtin_nontemporal_store(c[ct][r], q); else *q = c[ct][r];
+      }
+  };
+  d4v c0[CT], c1[CT], c2[CT];
+  double a0[NG], a1[NG], a2[NG];
+  int t0, t1, t2;
+  {
+    const unsigned r0 = pull(), r1 = pull(), r2 = pull();
+    t0 = take(r0); t1 = take(r1); t2 = take(r2);
+  }
+  if (t0 < ntiles) load_tile(t0, c0, a0);
+  if (t1 < ntiles) load_tile(t1, c1, a1);
+#pragma unroll 1
+  while (t0 < ntiles) {   // tickets only grow: t0 >= ntiles means nothing is left for this wave
+    const unsigned r3 = pull();
+    if (t2 < ntiles) load_tile(t2, c2, a2);
+    __builtin_amdgcn_sched_barrier(0);
+    work_tile(t0, c0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int t3 = take(r3);
+    if (t1 >= ntiles) break;
+    const unsigned r4 = pull();
+    if (t3 < ntiles) load_tile(t3, c0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    work_tile(t1, c1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int t4 = take(r4);
+    if (t2 >= ntiles) break;
+    const unsigned r5 = pull();
+    if (t4 < ntiles) load_tile(t4, c1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    work_tile(t2, c2, a2);
+    __builtin_amdgcn_sched_barrier(0);
+    const int t5 = take(r5);
+    t0 = t3; t1 = t4; t2 = t5;
+  }
+}
+#endif  // LPX_FUSED
+
 // ---- 64 pivots per pass: two stages of 32 inside one workgroup ------------------------------------------------------
 // At K = 32 the sweep is bound by memory (16 m n bytes per pass at ~5 TB/s), not by the 2 m n K unfused fp64
 // operations; twice the pivots per pass halves the bytes per pivot.  A thread cannot hold 64 pivot-row slices (256
@@ -3495,7 +3816,10 @@ __device__ __forceinline__ double apply_pivot(double v, int i, int j, int l_r, i
 }
 
 // After the sweep: recompute the entering columns (job 0), the pivot rows (job 1) and b (job 2) of the valid
-// pending pivots from the saved stale values.  grid = (ceil(max(m, ld)/256), K, 3).
+// pending pivots from the saved stale values.  grid = (ceil(max(m, ld)/256), ceil(K / 8), 3): a thread takes EIGHT
+// pending pivots' columns (rows) of its row (column) at once, so that a ring value it loads serves eight chains (one
+// pivot per thread re-read the K x m / K x ld ring values K times over: 1.6 GB of L2 traffic per block of 64 at cfg4).
+constexpr int kFixChunk = 8;
 __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int64_t ld, int n, int m_local, int row0,
                                                      double* b, const double* __restrict__ prow_ring,
                                                      const double* __restrict__ col_ring,
@@ -3506,12 +3830,13 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
   if (clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     clk[2] = __builtin_amdgcn_s_memtime(); clk[3] = wall_clock64();
   }
-  __shared__ double sh_p[kBlockMax], sh_bl[kBlockMax], sh_x[kBlockMax];
+  __shared__ double sh_p[kBlockMax], sh_bl[kBlockMax];
+  __shared__ double sh_x[kBlockMax][kFixChunk];   // job 0: prow_r[e_s]; job 1: col_r[l_s]   (r: all pivots, s: this chunk's)
   __shared__ int sh_e[kBlockMax], sh_l[kBlockMax];
   __shared__ int sh_np;
-  const int s = blockIdx.y, job = blockIdx.z;
+  const int s0 = blockIdx.y * kFixChunk, job = blockIdx.z;
   const int np = ring_count(ring, kBlockMax, kmax, &sh_np);
-  if (job == 2 ? s != 0 : s >= np) return;  // the b job also runs for an empty block (out of place: it copies b)
+  if (job == 2 ? s0 != 0 : s0 >= np) return;  // the b job also runs for an empty block (out of place: it copies b)
   if ((int)threadIdx.x < np) {
     const LpxCtl& q = ring[threadIdx.x];
     sh_e[threadIdx.x] = q.e_cur;
@@ -3521,44 +3846,78 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
   }
   __syncthreads();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (job == 0) {  // entering column of pending pivot s, all local rows
-    const int j = sh_e[s];
-    if ((int)threadIdx.x < np) sh_x[threadIdx.x] = prow_ring[(int64_t)threadIdx.x * ld + j];
+  const int ns = min(kFixChunk, np - s0);   // pivots of this chunk (job 0 / 1)
+  if (job == 0) {  // entering columns of pending pivots s0 .. s0 + ns - 1, all local rows
+    for (int idx = threadIdx.x; idx < np * kFixChunk; idx += blockDim.x) {
+      const int r = idx / kFixChunk, q = idx % kFixChunk;
+      sh_x[r][q] = q < ns ? prow_ring[(int64_t)r * ld + sh_e[s0 + q]] : 0.0;
+    }
     __syncthreads();
     if (t < m_local) {
-      double v = col0_ring[(int64_t)s * mp + t];
-      // the ring values of eight steps are requested together (they do not depend on the running value): np / 8
-      // round trips instead of np
+      double v[kFixChunk];
+#pragma unroll
+      for (int q = 0; q < kFixChunk; ++q) v[q] = q < ns ? col0_ring[(int64_t)(s0 + q) * mp + t] : 0.0;
+      // the ring values of eight steps are requested together (they do not depend on the running values)
       for (int r0 = 0; r0 < np; r0 += 8) {
         double cv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) cv[q] = (r0 + q < np) ? col_ring[(int64_t)(r0 + q) * mp + t] : 0.0;
+        for (int u = 0; u < 8; ++u) cv[u] = (r0 + u < np) ? col_ring[(int64_t)(r0 + u) * mp + t] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = r0 + q;
-          if (r < np) v = apply_pivot(v, t, j, sh_l[r], sh_e[r], sh_p[r], cv[q], sh_x[r]);
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u;
+          if (r < np) {
+#pragma unroll
+            for (int q = 0; q < kFixChunk; ++q)
+              if (q < ns) {
+                // (the full case analysis of apply_pivot; the division only where a chain really takes it — same
+                // entering slot as pivot r: decided per (r, q), the same in every lane)
+                double nv;
+                if (sh_e[s0 + q] == sh_e[r]) nv = -__ddiv_rn(cv[u], sh_p[r]);                 // :157
+                else nv = submul(v[q], cv[u], sh_x[r][q]);                                    // :162
+                v[q] = (t == sh_l[r]) ? sh_x[r][q] : nv;   // pivot row := normalised row
+              }
+          }
         }
       }
-      A[(int64_t)t * ld + j] = v;
+#pragma unroll
+      for (int q = 0; q < kFixChunk; ++q)
+        if (q < ns) A[(int64_t)t * ld + sh_e[s0 + q]] = v[q];
     }
-  } else if (job == 1) {  // pivot row of pending pivot s (if it lives on this shard), all columns
-    const int i = sh_l[s];
-    if (i < 0 || i >= m_local) return;
-    if ((int)threadIdx.x < np) sh_x[threadIdx.x] = col_ring[(int64_t)threadIdx.x * mp + i];
+  } else if (job == 1) {  // pivot rows of pending pivots s0 .. (those that live on this shard), all columns
+    for (int idx = threadIdx.x; idx < np * kFixChunk; idx += blockDim.x) {
+      const int r = idx / kFixChunk, q = idx % kFixChunk;
+      const int i = q < ns ? sh_l[s0 + q] : -1;
+      sh_x[r][q] = (i >= 0 && i < m_local) ? col_ring[(int64_t)r * mp + i] : 0.0;
+    }
     __syncthreads();
     if (t < (int)ld) {
-      double v = t < n ? row0_ring[(int64_t)s * ld + t] : 0.0;
+      double v[kFixChunk];
+#pragma unroll
+      for (int q = 0; q < kFixChunk; ++q) v[q] = (q < ns && t < n) ? row0_ring[(int64_t)(s0 + q) * ld + t] : 0.0;
       for (int r0 = 0; r0 < np; r0 += 8) {
         double pv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pv[q] = (r0 + q < np) ? prow_ring[(int64_t)(r0 + q) * ld + t] : 0.0;
+        for (int u = 0; u < 8; ++u) pv[u] = (r0 + u < np) ? prow_ring[(int64_t)(r0 + u) * ld + t] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = r0 + q;
-          if (r < np) v = apply_pivot(v, i, t, sh_l[r], sh_e[r], sh_p[r], sh_x[r], pv[q]);
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u;
+          if (r < np) {
+#pragma unroll
+            for (int q = 0; q < kFixChunk; ++q)
+              if (q < ns) {
+                double nv;
+                if (t == sh_e[r]) nv = -__ddiv_rn(sh_x[r][q], sh_p[r]);   // (one thread of the grid per pivot r)
+                else nv = submul(v[q], sh_x[r][q], pv[u]);
+                v[q] = (sh_l[s0 + q] == sh_l[r]) ? pv[u] : nv;
+              }
+          }
         }
       }
-      A[(int64_t)i * ld + t] = v;
+#pragma unroll
+      for (int q = 0; q < kFixChunk; ++q) {
+        const int i = q < ns ? sh_l[s0 + q] : -1;
+        if (i >= 0 && i < m_local) A[(int64_t)i * ld + t] = v[q];
+      }
     }
   } else {  // b of every local row (LPState.java:164 / :146)
     if (t < m_local) {
@@ -3874,7 +4233,7 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
 // no rows, no decisions) and touch nothing but the ring's own words.
 // The ticket buffer: one 128-byte slot per 128-column sub-strip (at least the four the preparing launches pull from),
 // then spare slots; the LAST slot is never a counter — it is the word a pull kernel sets when a bounded wait ran out.
-int64_t sweep_ticket_slots(int64_t ld) { return std::max<int64_t>(ld / 128, 4) + 4; }
+int64_t sweep_ticket_slots(int64_t ld) { return std::max<int64_t>(ld / 64, 4) + 4; }   // (k_sweep64_one: a counter per 64 columns)
 unsigned* sweep_fail_word(const BlockRing& R, int64_t ld) {
   return R.tickets ? R.tickets + (sweep_ticket_slots(ld) - 1) * 32 : nullptr;
 }
@@ -3916,6 +4275,17 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
     hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, (sweep_fail_word)(R, ld));
     LPX_EACH_NT_OOP(LPX_PRE_PULL64)
 #undef LPX_PRE_PULL64
+#define LPX_PRE_ONE64(NT_, OOP_) \
+    hipLaunchKernelGGL((k_sweep64_one<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
+    LPX_EACH_NT_OOP(LPX_PRE_ONE64)
+#undef LPX_PRE_ONE64
+#if LPX_FUSED
+    hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr);
+#define LPX_PRE_MFMA64(NT_, OOP_) \
+    hipLaunchKernelGGL((k_sweep64_mfma<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
+    LPX_EACH_NT_OOP(LPX_PRE_MFMA64)
+#undef LPX_PRE_MFMA64
+#endif
   }
 #undef LPX_PRE_PULL
 #undef LPX_PRE_DMA
@@ -4063,6 +4433,45 @@ static void launch_sweep64_pull(const Buffers& B, const BlockRing& R, int m_loca
 #undef LPX_LAUNCH_PULL64
 }
 
+// blocks of 33..64 by single waves on 64-column sub-strips (k_sweep64_one); G workgroups per group of four sub-strips
+static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
+                               hipStream_t s, int slots = 512) {
+  const int nstrips_full = (int)(B.ld / 512);
+  const int ngroups = nstrips_full * 2;
+  const int nbt = m_local / 4;
+  const int G = std::max(1, std::min(nbt, slots / std::max(1, ngroups)));
+  hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed,
+                     R.tickets, nstrips_full * 8, R.clk);
+  const dim3 grid(ngroups * G), block(256);
+#define LPX_LAUNCH_ONE64(NT_, OOP_)                                                                               \
+  hipLaunchKernelGGL((k_sweep64_one<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
+                     nstrips_full, R.col_packed, R.tickets)
+  if (A_src) { if (nt) LPX_LAUNCH_ONE64(true, true); else LPX_LAUNCH_ONE64(false, true); }
+  else { if (nt) LPX_LAUNCH_ONE64(true, false); else LPX_LAUNCH_ONE64(false, false); }
+#undef LPX_LAUNCH_ONE64
+}
+
+#if LPX_FUSED
+// blocks of 33..64 on the matrix cores (fused arithmetic only): one wave per SIMD, G workgroups per group of four
+// 64-column sub-strips, 16-row tiles pulled from the sub-strip's ticket counter
+static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
+                                hipStream_t s, int slots = 256) {
+  const int nstrips_full = (int)(B.ld / 512);
+  const int ngroups = nstrips_full * 2;
+  const int ntiles = m_local / 16;
+  const int G = std::max(1, std::min(ntiles, slots / std::max(1, ngroups)));
+  hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, s, R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
+                     R.tickets, nstrips_full * 8, R.clk);
+  const dim3 grid(ngroups * G), block(256);
+#define LPX_LAUNCH_MFMA64(NT_, OOP_)                                                                               \
+  hipLaunchKernelGGL((k_sweep64_mfma<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
+                     nstrips_full, R.col_packed, R.tickets)
+  if (A_src) { if (nt) LPX_LAUNCH_MFMA64(true, true); else LPX_LAUNCH_MFMA64(false, true); }
+  else { if (nt) LPX_LAUNCH_MFMA64(true, false); else LPX_LAUNCH_MFMA64(false, false); }
+#undef LPX_LAUNCH_MFMA64
+}
+#endif
+
 static void launch_sweep64_pipe(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
                                 const double* A_src, hipStream_t s) {
   const int nstrips_full = (int)(B.ld / 512);
@@ -4132,6 +4541,8 @@ const char* sweep_kernel_name(int code) {
     case kSweepDma: return "k_sweep32_dma";
     case kSweepPull: return "k_sweep32_pull";
     case kSweepPull64: return "k_sweep64_pull";
+    case kSweepOne64: return "k_sweep64_one";
+    case kSweepMfma64: return "k_sweep64_mfma";
     default: return "";
   }
 }
@@ -4167,10 +4578,25 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     const int nstrips_full = (int)(B.ld / 512);
     // (the pull kernels address a batch's rows by 32-bit byte offsets: 3 * ld * 8 + 1 KiB must stay below 2^32)
     const bool geom = m_local % 4 == 0 && nstrips_full >= 1 && 3 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
-    const bool pull = geom && form != 1 && R.tickets && R.col_packed;   // round 3: blocks of 33..64 valid pivots
+    const bool pull = geom && form != 1 && R.tickets && R.col_packed;   // round 3 / 4: blocks of 33..64 valid pivots
     const bool pipe = geom && !pull && K == 64;                         // round 2: full blocks of 64 only
+    // round 4: one wave per 64-column sub-strip (form 0, the default); form 2: the pair of waves of round 3
+    const bool one = pull && form != 2;
+    // round 4, fused arithmetic: the matrix cores (form 0; 16-row tiles; form 3 = k_sweep64_one there)
+    bool mfma = false;
+#if LPX_FUSED
+    mfma = one && form == 0 && m_local % 16 == 0 && 16 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
+#endif
     int rows64 = 0;
-    if (pull) {
+    if (mfma) {
+#if LPX_FUSED
+      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus);
+#endif
+      rows64 = 16;
+    } else if (one) {
+      launch_sweep64_one(B, R, m_local, K, nt, A_src, s, 2 * cus);
+      rows64 = 4;
+    } else if (pull) {
       launch_sweep64_pull(B, R, m_local, K, nt, A_src, s, 2 * cus);
       rows64 = 4;
     } else if (pipe) {
@@ -4186,7 +4612,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, complement, 0);
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, complement, 32);
     rows_per_wg = (pull || pipe) ? rows64 : rows;
-    used = pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti);
+    used = mfma ? kSweepMfma64 : one ? kSweepOne64 : (pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti));
 #ifndef LPX_STEADY_PARTIAL
 #define LPX_STEADY_PARTIAL 1
 #endif
@@ -4244,7 +4670,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
   if (kernel_used) *kernel_used = used;
   if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
-  hipLaunchKernelGGL(k_block_fixup, dim3(gx, K, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
+  hipLaunchKernelGGL(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
                      R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, R.clk);
   return rows_per_wg;
 }

@@ -1167,16 +1167,18 @@ def test_soak_repeated_runs_on_the_shape_that_exposed_the_stale_read(lps, oracle
 
 
 @pytest.mark.parametrize("shape", [(1000, 2100), (4100, 1024), (8, 512), (2052, 4100)])
-@pytest.mark.parametrize("block,kernel", [(21, "k_sweep32_pull"), (32, "k_sweep32_pull"), (40, "k_sweep64_pull"),
-                                          (64, "k_sweep64_pull")])
-def test_pulled_sweep_kernels_on_ragged_shapes(lps, oracle, shape, block, kernel):
-    """The ticket-pulling sweep kernels (one wave / one pair of waves per 128-column sub-strip worker) on shapes with a
-    partial last strip, a last batch count that is not a multiple of anything, fewer batches than workers, and blocks
-    that are only partly filled (21 of 32, 40 of 64 steps are real, the rest identities): bit-exact vs the fp64
-    oracle after every budget; the engine must report the kernel that is expected to have run."""
+@pytest.mark.parametrize("block,form,kernel", [(21, 0, "k_sweep32_pull"), (32, 0, "k_sweep32_pull"),
+                                               (40, 0, "k_sweep64_one"), (64, 0, "k_sweep64_one"),
+                                               (40, 2, "k_sweep64_pull"), (64, 2, "k_sweep64_pull")])
+def test_pulled_sweep_kernels_on_ragged_shapes(lps, oracle, shape, block, form, kernel):
+    """The ticket-pulling sweep kernels (one wave per 128-column sub-strip for blocks up to 32; one wave per 64-column
+    sub-strip — or, sweep_form 2, a pair of waves per 128 columns — for blocks of 33..64) on shapes with a partial last
+    strip, a last batch count that is not a multiple of anything, fewer batches than workers, and blocks that are only
+    partly filled (21 of 32, 40 of 64 steps are real, the rest identities): bit-exact vs the fp64 oracle after every
+    budget; the engine must report the kernel that is expected to have run."""
     m, n = shape
     A, b, c = dense_lp(m, n, seed=11 * m + n)
-    st = lps.LPState(A, b, c, block=block)
+    st = lps.LPState(A, b, c, block=block, options={"sweep_form": form})
     ref = oracle.State(A, b, c, kind=oracle.FP64)
     for budget in (block - 1, 2 * block + 5, block - 1):   # a full block of `block` decisions (block - 1 pivots + the probe)
         status, pivots, _ = st.simplex_loop(max_pivots=budget)
@@ -1185,4 +1187,25 @@ def test_pulled_sweep_kernels_on_ragged_shapes(lps, oracle, shape, block, kernel
         assert_state_bits_equal(st.read(), ref.read(), "block %d budget %d of %s" % (block, budget, shape))
     if status == 9:   # still running: the last sweep applied block - 1 >= 17 pivots
         assert st.info()["sweep_kernel_name"] == kernel, st.info()
+    st.close()
+
+
+@pytest.mark.parametrize("shape", [(1024, 2112), (2048, 4100), (4096, 1024), (16, 512)])
+@pytest.mark.parametrize("block", [40, 64])
+def test_blocks_of_33_to_64_with_16_row_tiles(lps, oracle, arith, shape, block):
+    """Tableaus whose height is a multiple of 16: in the fused-arithmetic mode blocks of 33..64 go through the matrix
+    cores (k_sweep64_mfma: v_mfma_f64_16x16x4 is a chain of fused multiply-adds in pivot order, so the bits are those of
+    64 v_fma_f64 steps), in the default arithmetic through k_sweep64_one; partly filled blocks, a partial last strip,
+    fewer tiles than workers: bit-exact against the oracle of the mode after every budget."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=17 * m + n)
+    st = lps.LPState(A, b, c, block=block)
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (block - 1, 2 * block + 5, block - 1):
+        status, pivots, _ = st.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget, threads=8)
+        assert (status, pivots) == (want["status"], want["pivots"]), (shape, block, budget)
+        assert_state_bits_equal(st.read(), ref.read(), "block %d budget %d of %s" % (block, budget, shape))
+    if status == 9 and n >= 512:
+        assert st.info()["sweep_kernel_name"] == ("k_sweep64_mfma" if arith == "fused" else "k_sweep64_one"), st.info()
     st.close()
