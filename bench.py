@@ -84,7 +84,9 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
            "traffic": traffic, "traffic_source": traffic_source,
            "kernel": kernel, "avg_kernel_ms": avg_ms, "launches_sampled": launches,
            "pivots_per_launch": pivots_per_launch,
-           "arithmetic": "fused (one v_fma_f64 per entry and pivot)" if fused else "two roundings (v_mul_f64 + v_add_f64 per entry and pivot)",
+           "arithmetic": ("fused (four pivots per v_mfma_f64_16x16x4 = a chain of four fused multiply-adds per entry)"
+                          if fused and kernel in ("k_sweep64_mfma", "k_sweep64_mfma2") else "fused (one v_fma_f64 per entry and pivot)" if fused
+                          else "two roundings (v_mul_f64 + v_add_f64 per entry and pivot)"),
            "clock_ghz": clock_ghz,
            "cycles_per_launch": t * clock_ghz * 1e9 if clock_ghz else None,
            "lower_bound_ms": {"hbm": 1e3 * t_hbm, "fp64_valu": 1e3 * t_valu, "fp64_valu_at_clock": 1e3 * t_valu_clk},
@@ -752,11 +754,14 @@ def main():
                             st=r_first["st"], done=r_first["done"])
             return measured(rs, mw, nw, name, Aw, bw, cw, with_parity), rs["done"]
 
-        def fused_leg(Aw, bw, cw, mw, nw, name):
+        def fused_leg(Aw, bw, cw, mw, nw, name, block=None):
             """The same steady-state protocol on a FRESH handle in the opt-in fused-arithmetic mode (LPX_OPT_FUSED: every
-            update one v_fma_f64), replayed on the oracle's fused instantiation."""
-            rf = run_single(Aw, bw, cw, mw, nw, steps=args.steady_steps, warmup=args.steady_warmup,
-                            opts=dict(options, fused=1))
+            update one v_fma_f64 — or, in blocks of 33..64, four of them per v_mfma_f64_16x16x4), replayed on the oracle's
+            fused instantiation.  block: pivots per sweep (None: by size)."""
+            fo = dict(options, fused=1)
+            if block is not None:
+                fo["block"] = block
+            rf = run_single(Aw, bw, cw, mw, nw, steps=args.steady_steps, warmup=args.steady_warmup, opts=fo)
             try:
                 return measured(rf, mw, nw, name, Aw, bw, cw, not args.no_parity)
             finally:
@@ -818,6 +823,11 @@ def main():
                 steady_fused["cfg4"] = fused_leg(A, b, c, m, n, "cfg4")
             except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
                 steady_fused["cfg4"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            try:   # the same with blocks of 32 (k_sweep32_pull, one v_fma_f64 per entry and pivot): the by-size choice
+                   # above is blocks of 64 on the matrix cores
+                steady_fused["cfg4_block32"] = fused_leg(A, b, c, m, n, "cfg4", block=32)
+            except Exception as ex:   # noqa: BLE001
+                steady_fused["cfg4_block32"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if single and args.workload == "cfg4" and not args.no_cfg3:
             # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
             # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)

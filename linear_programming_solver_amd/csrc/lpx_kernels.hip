@@ -3665,6 +3665,119 @@ __global__ __launch_bounds__(256, 1) void k_sweep64_mfma(double* __restrict__ A,
     t0 = t3; t1 = t4; t2 = t5;
   }
 }
+
+// Second form: TWO waves per SIMD.  k_sweep64_mfma keeps the B operands in 128 VGPRs and therefore runs one wave per
+// SIMD: while that wave issues a tile's 48 loads and 16 stores and waits for the last MFMAs of a tile, the matrix pipe
+// idles (measured: 2.3 ms per 64 pivots at cfg4 against 1.45 ms of arithmetic).  Here a workgroup is bound to a
+// 128-column group, its four waves to the two 64-column sub-strips in pairs, and the B operands of both sub-strips live
+// in LDS (2 x 32 KiB, [sub-strip][group][column tile][lane]: every MFMA's B is one conflict-free ds_read_b64 with an
+// immediate offset); the registers hold three tiles of C and A.  Two workgroups per CU.
+constexpr int kMfma2LdsBytes = 2 * 16 * 4 * 64 * 8;
+static_assert(2 * kMfma2LdsBytes <= 160 * 1024, "two workgroups per CU");
+template <bool NT, bool OOP>
+__global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A, const double* __restrict__ Asrc,
+                                                          int64_t ld, int m_local,
+                                                          const double* __restrict__ prow_ring,
+                                                          const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
+                                                          const double* __restrict__ colM,   // [tile][group][lane]
+                                                          unsigned* __restrict__ tickets) {
+  constexpr int NG = 16, CT = 4;
+  __shared__ __attribute__((aligned(16))) double sh_b[2 * NG * CT * 64];
+  __shared__ int sh_np;
+  const int np = ring_count(ring, 64, kmax, &sh_np);
+  if (np <= 32) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int ngroups = nstrips_full * 4;            // groups of 128 columns
+  const int grp = (ngroups % 8 == 0)
+                      ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(ngroups / 8)) % (unsigned)ngroups)
+                      : (int)(blockIdx.x % (unsigned)ngroups);
+  const int half = wave >> 1;                      // which of the group's two sub-strips this wave works on
+  const int sub = grp * 2 + half;
+  const int ntiles = m_local / 16;
+  unsigned* const ctr = tickets + sub * 32;
+  const int64_t row_bytes = ld * 8;
+  char* const dst_base = reinterpret_cast<char*>(A + sub * 64);
+  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + sub * 64) : dst_base;
+  const uint32_t rb32 = (uint32_t)row_bytes;
+  const uint32_t off_c = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 8u;
+  // the B operands of the wave's sub-strip into LDS: the pair of waves shares the 64 (group, column tile) images
+  double* const myb = sh_b + half * (NG * CT * 64);
+  for (int q = (wave & 1); q < NG * CT; q += 2) {
+    const int g = q / CT, ct = q % CT;
+    const int s = 4 * g + (lane >> 4);
+    myb[q * 64 + lane] = s < np ? prow_ring[(int64_t)s * ld + sub * 64 + ct * 16 + (lane & 15)] : 0.0;
+  }
+  __syncthreads();
+  const double* const bl = myb + lane;
+  auto pull = [&]() -> unsigned {
+    unsigned t = 0;
+    if (lane == 0) t = atomicAdd(ctr, 1u);
+    return t;
+  };
+  auto take = [&](unsigned raw) -> int { return __builtin_amdgcn_readfirstlane((int)raw); };
+  auto load_tile = [&](int t, d4v (&c)[CT], double (&a)[NG]) {
+    const char* const base = src_base + (int64_t)t * 16 * row_bytes;   // uniform
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const double* q = reinterpret_cast<const double*>(base + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
+        c[ct][r] = NT ? __builtin_nontemporal_load(q) : *q;
+      }
+    const double* const am = colM + (int64_t)t * 1024 + lane;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a[g] = am[g * 64];
+  };
+  auto work_tile = [&](int t, d4v (&c)[CT], const double (&a)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+        c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bl[(g * CT + ct) * 64], c[ct], 0, 0, 0);
+    char* const out = dst_base + (int64_t)t * 16 * row_bytes;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        double* q = reinterpret_cast<double*>(out + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
+        if (NT) __builtin_nontemporal_store(c[ct][r], q); else *q = c[ct][r];
+      }
+  };
+  d4v c0[CT], c1[CT], c2[CT];
+  double a0[NG], a1[NG], a2[NG];
+  int t0, t1, t2;
+  {
+    const unsigned r0 = pull(), r1 = pull(), r2 = pull();
+    t0 = take(r0); t1 = take(r1); t2 = take(r2);
+  }
+  if (t0 < ntiles) load_tile(t0, c0, a0);
+  if (t1 < ntiles) load_tile(t1, c1, a1);
+#pragma unroll 1
+  while (t0 < ntiles) {
+    const unsigned r3 = pull();
+    if (t2 < ntiles) load_tile(t2, c2, a2);
+    __builtin_amdgcn_sched_barrier(0);
+    work_tile(t0, c0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int t3 = take(r3);
+    if (t1 >= ntiles) break;
+    const unsigned r4 = pull();
+    if (t3 < ntiles) load_tile(t3, c0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    work_tile(t1, c1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    const int t4 = take(r4);
+    if (t2 >= ntiles) break;
+    const unsigned r5 = pull();
+    if (t4 < ntiles) load_tile(t4, c1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    work_tile(t2, c2, a2);
+    __builtin_amdgcn_sched_barrier(0);
+    const int t5 = take(r5);
+    t0 = t3; t1 = t4; t2 = t5;
+  }
+}
 #endif  // LPX_FUSED
 
 // ---- 64 pivots per pass: two stages of 32 inside one workgroup ------------------------------------------------------
@@ -4285,6 +4398,10 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
     hipLaunchKernelGGL((k_sweep64_mfma<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
     LPX_EACH_NT_OOP(LPX_PRE_MFMA64)
 #undef LPX_PRE_MFMA64
+#define LPX_PRE_MFMA642(NT_, OOP_) \
+    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
+    LPX_EACH_NT_OOP(LPX_PRE_MFMA642)
+#undef LPX_PRE_MFMA642
 #endif
   }
 #undef LPX_PRE_PULL
@@ -4455,13 +4572,25 @@ static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local
 // blocks of 33..64 on the matrix cores (fused arithmetic only): one wave per SIMD, G workgroups per group of four
 // 64-column sub-strips, 16-row tiles pulled from the sub-strip's ticket counter
 static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                                hipStream_t s, int slots = 256) {
+                                hipStream_t s, int slots = 256, bool two_waves = false) {
   const int nstrips_full = (int)(B.ld / 512);
   const int ngroups = nstrips_full * 2;
   const int ntiles = m_local / 16;
   const int G = std::max(1, std::min(ntiles, slots / std::max(1, ngroups)));
   hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, s, R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
                      R.tickets, nstrips_full * 8, R.clk);
+  if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
+    const int ng2 = nstrips_full * 4;
+    const int G2 = std::max(1, std::min(ntiles, 2 * slots / std::max(1, ng2)));
+    const dim3 grid2(ng2 * G2), block2(256);
+#define LPX_LAUNCH_MFMA642(NT_, OOP_)                                                                               \
+    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), grid2, block2, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
+                       nstrips_full, R.col_packed, R.tickets)
+    if (A_src) { if (nt) LPX_LAUNCH_MFMA642(true, true); else LPX_LAUNCH_MFMA642(false, true); }
+    else { if (nt) LPX_LAUNCH_MFMA642(true, false); else LPX_LAUNCH_MFMA642(false, false); }
+#undef LPX_LAUNCH_MFMA642
+    return;
+  }
   const dim3 grid(ngroups * G), block(256);
 #define LPX_LAUNCH_MFMA64(NT_, OOP_)                                                                               \
   hipLaunchKernelGGL((k_sweep64_mfma<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
@@ -4543,6 +4672,7 @@ const char* sweep_kernel_name(int code) {
     case kSweepPull64: return "k_sweep64_pull";
     case kSweepOne64: return "k_sweep64_one";
     case kSweepMfma64: return "k_sweep64_mfma";
+    case kSweepMfma642: return "k_sweep64_mfma2";
     default: return "";
   }
 }
@@ -4582,15 +4712,16 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     const bool pipe = geom && !pull && K == 64;                         // round 2: full blocks of 64 only
     // round 4: one wave per 64-column sub-strip (form 0, the default); form 2: the pair of waves of round 3
     const bool one = pull && form != 2;
-    // round 4, fused arithmetic: the matrix cores (form 0; 16-row tiles; form 3 = k_sweep64_one there)
+    // round 4, fused arithmetic: the matrix cores (16-row tiles): form 0 = k_sweep64_mfma2 (two waves per SIMD, B operands
+    // in LDS: 2.12 vs 2.33 ms per 64 pivots at cfg4), form 4 = k_sweep64_mfma (one wave per SIMD); form 3 = k_sweep64_one there
     bool mfma = false;
 #if LPX_FUSED
-    mfma = one && form == 0 && m_local % 16 == 0 && 16 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
+    mfma = one && (form == 0 || form == 4) && m_local % 16 == 0 && 16 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
 #endif
     int rows64 = 0;
     if (mfma) {
 #if LPX_FUSED
-      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus);
+      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, form == 0);   // form 4: one wave per SIMD (k_sweep64_mfma)
 #endif
       rows64 = 16;
     } else if (one) {
@@ -4612,7 +4743,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, complement, 0);
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, complement, 32);
     rows_per_wg = (pull || pipe) ? rows64 : rows;
-    used = mfma ? kSweepMfma64 : one ? kSweepOne64 : (pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti));
+    used = mfma ? (form == 0 ? kSweepMfma642 : kSweepMfma64) : one ? kSweepOne64 : (pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti));
 #ifndef LPX_STEADY_PARTIAL
 #define LPX_STEADY_PARTIAL 1
 #endif

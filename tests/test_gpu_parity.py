@@ -914,22 +914,25 @@ def test_cfg3_sweep_forms_vs_fp64_oracle(lps, oracle, form, name):
     assert info["block"] == 32 and info["sweep_kernel_name"] == name
 
 
-def test_cfg4_timed_form_70_pivots_vs_fp64_oracle(lps, oracle):
+def test_cfg4_timed_form_70_pivots_vs_fp64_oracle(lps, oracle, arith):
     """BASELINE cfg4 (32768 x 16384, 4 GiB): 25 pivots (the driver's bench command is 5 + 20: a budget that fits one
     block goes through the serial form on the whole chip), then two full K = 32 blocks + a tail, then a full block + a
     partly filled one through the default overlapped loop, every time against the fp64 oracle."""
     info = _timed_form_vs_oracle(lps, oracle, 32768, 16384, (25, 70, 50))   # (the last sweep: 18 pivots, padded to 32)
-    assert info["block"] == 32 and info["overlapped"] == 1 and info["nontemporal"] == 1
-    assert info["sweep_kernel_name"] == "k_sweep32_pull"
+    # by size: blocks of 32 (k_sweep32_pull); in the fused-arithmetic mode blocks of 64 on the matrix cores from ~2.5 GiB
+    # (there the last sweep of this test, 18 pivots of a block of 64, is two generic passes)
+    assert info["block"] == (64 if arith == "fused" else 32) and info["overlapped"] == 1 and info["nontemporal"] == 1
+    if arith != "fused":
+        assert info["sweep_kernel_name"] == "k_sweep32_pull"
     assert info["chain_wgs"] <= info["chain_resident_max"]
     print("cfg4 placement:", info)
 
 
-def test_tableau_beyond_4_gib_vs_fp64_oracle(lps, oracle):
+def test_tableau_beyond_4_gib_vs_fp64_oracle(lps, oracle, arith):
     """36864 x 18432 = 5.4 GB per tableau buffer: byte offsets beyond 2^32 in the sweeps (32-bit offsets are per run of
     rows only), the decision kernel's strided column reads and the fix-up, 40 pivots through the default loop."""
     info = _timed_form_vs_oracle(lps, oracle, 36864, 18432, (40,))
-    assert info["block"] == 32 and info["overlapped"] == 1
+    assert info["block"] == (64 if arith == "fused" else 32) and info["overlapped"] == 1
 
 
 def test_8_gib_tableau_takes_blocks_of_64_by_size(lps, oracle):
@@ -1191,15 +1194,16 @@ def test_pulled_sweep_kernels_on_ragged_shapes(lps, oracle, shape, block, form, 
 
 
 @pytest.mark.parametrize("shape", [(1024, 2112), (2048, 4100), (4096, 1024), (16, 512)])
+@pytest.mark.parametrize("form", [0, 4])
 @pytest.mark.parametrize("block", [40, 64])
-def test_blocks_of_33_to_64_with_16_row_tiles(lps, oracle, arith, shape, block):
+def test_blocks_of_33_to_64_with_16_row_tiles(lps, oracle, arith, shape, block, form):
     """Tableaus whose height is a multiple of 16: in the fused-arithmetic mode blocks of 33..64 go through the matrix
     cores (k_sweep64_mfma: v_mfma_f64_16x16x4 is a chain of fused multiply-adds in pivot order, so the bits are those of
     64 v_fma_f64 steps), in the default arithmetic through k_sweep64_one; partly filled blocks, a partial last strip,
     fewer tiles than workers: bit-exact against the oracle of the mode after every budget."""
     m, n = shape
     A, b, c = dense_lp(m, n, seed=17 * m + n)
-    st = lps.LPState(A, b, c, block=block)
+    st = lps.LPState(A, b, c, block=block, options={"sweep_form": form})   # (fused: 0 = two waves per SIMD, 4 = one)
     ref = oracle.State(A, b, c, kind=oracle.FP64)
     for budget in (block - 1, 2 * block + 5, block - 1):
         status, pivots, _ = st.simplex_loop(max_pivots=budget)
@@ -1207,5 +1211,6 @@ def test_blocks_of_33_to_64_with_16_row_tiles(lps, oracle, arith, shape, block):
         assert (status, pivots) == (want["status"], want["pivots"]), (shape, block, budget)
         assert_state_bits_equal(st.read(), ref.read(), "block %d budget %d of %s" % (block, budget, shape))
     if status == 9 and n >= 512:
-        assert st.info()["sweep_kernel_name"] == ("k_sweep64_mfma" if arith == "fused" else "k_sweep64_one"), st.info()
+        want_kernel = ("k_sweep64_mfma2" if form == 0 else "k_sweep64_mfma") if arith == "fused" else "k_sweep64_one"
+        assert st.info()["sweep_kernel_name"] == want_kernel, st.info()
     st.close()
