@@ -15,6 +15,11 @@ final class LpxNative {
 
   private LpxNative() {}
 
+  /** Arithmetic of every handle created afterwards (lpx.h LPX_OPT_FUSED / lpx_solve_options.fused): false (default) =
+   *  product and difference of every update rounded separately, as the reference's BigDecimal code rounds them
+   *  (LPState.java:162); true = fused multiply-add updates (one binary rounding; faster sweeps, same tolerance class). */
+  static native void setFusedArithmetic(boolean on);
+
   /** lpx_solve — replaces LPSolver.solve(LPStandardForm) (LPSolver.java:78).
    *  a: row-major m*n.  restoreOrder: iteration order of stForm.coefficients.keySet() as variable indices
    *  (null: the default-name order).  out[0] = unrounded objective, out[1] = objective rounded to 6 decimals

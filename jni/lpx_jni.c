@@ -9,6 +9,14 @@
 
 #define NAME(fn) Java_lpsolver_LpxNative_##fn
 
+/* Arithmetic of the handles this shim creates (LpxNative.setFusedArithmetic): 0 = product and difference of every
+ * update rounded separately, as the reference rounds them (default); 1 = fused multiply-add updates (LPX_OPT_FUSED). */
+static int g_fused = 0;
+JNIEXPORT void JNICALL NAME(setFusedArithmetic)(JNIEnv* env, jclass cls, jboolean on) {
+  (void)env; (void)cls;
+  g_fused = on ? 1 : 0;
+}
+
 static double* get_d(JNIEnv* env, jdoubleArray a) { return a ? (*env)->GetDoubleArrayElements(env, a, NULL) : NULL; }
 static void put_d(JNIEnv* env, jdoubleArray a, double* p, jint mode) { if (a && p) (*env)->ReleaseDoubleArrayElements(env, a, p, mode); }
 static jint* get_i(JNIEnv* env, jintArray a) { return a ? (*env)->GetIntArrayElements(env, a, NULL) : NULL; }
@@ -23,6 +31,7 @@ JNIEXPORT jint JNICALL NAME(solve)(JNIEnv* env, jclass cls, jint m, jint n, jdou
   jint* perm = get_i(env, jperm);
   lpx_solve_options opts = {0};
   opts.device = 0;
+  opts.fused = g_fused;
   opts.max_pivots = -1;
   opts.restore_order = (const int32_t*)order;
   opts.restore_order_len = jorder ? (int32_t)(*env)->GetArrayLength(env, jorder) : 0;
@@ -55,6 +64,7 @@ JNIEXPORT jint JNICALL NAME(solveMulti)(JNIEnv* env, jclass cls, jint m, jint n,
   jint* perm = get_i(env, jperm);
   lpx_solve_options opts = {0};
   opts.max_pivots = -1;
+  opts.fused = g_fused;
   opts.restore_order = (const int32_t*)order;
   opts.restore_order_len = jorder ? (int32_t)(*env)->GetArrayLength(env, jorder) : 0;
   opts.perm_out = (int32_t*)perm;
@@ -82,6 +92,7 @@ JNIEXPORT jlong JNICALL NAME(stateCreate)(JNIEnv* env, jclass cls, jint m, jint 
   jint* perm = get_i(env, jperm);
   lpx_state* s = NULL;
   int rc = lpx_state_create(m, n, a, n, b, c, v, (const int32_t*)perm, 0, m, 0, &s);
+  if (rc == 0 && g_fused) rc = lpx_state_set_option(s, LPX_OPT_FUSED, 1);
   put_d(env, ja, a, JNI_ABORT); put_d(env, jb, b, JNI_ABORT); put_d(env, jc, c, JNI_ABORT);
   put_i(env, jperm, perm, JNI_ABORT);
   return rc == 0 ? (jlong)(intptr_t)s : 0;

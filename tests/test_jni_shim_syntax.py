@@ -21,6 +21,23 @@ def test_jni_shim_type_checks_against_lpx_h(cc):
     subprocess.check_call([cc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", STUB, SHIM])
 
 
+def test_jni_shim_compiles_and_links_against_liblpx(tmp_path):
+    """Beyond the syntax check: the shim is compiled to an object and LINKED into a shared library against the built
+    liblpx.so with -Wl,--no-undefined — every lpx_* symbol the shim calls must be exported by the library (the JNIEnv
+    function table is a struct of pointers: nothing else is left unresolved).  No JDK is needed for that, only the
+    stub <jni.h>; loading it into a JVM remains untested (none in the image)."""
+    lib = os.path.join(ROOT, "linear_programming_solver_amd", "liblpx.so")
+    if not os.path.exists(lib) or shutil.which("gcc") is None:
+        pytest.skip("liblpx.so not built / gcc not available")
+    out = tmp_path / "liblpxjni.so"
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-shared", "-fPIC", "-I", STUB, SHIM, "-o", str(out),
+           "-Wl,--no-undefined", "-Wl,--allow-shlib-undefined", lib]
+    subprocess.check_call(cmd)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", str(out)], text=True)
+    for name in re.findall(r"NAME\((\w+)\)\(", open(SHIM).read()):
+        assert "Java_lpsolver_LpxNative_" + name in syms, name
+
+
 def test_every_native_method_of_the_java_class_has_a_c_definition():
     """jni/java/lpsolver/LpxNative.java declares the native methods; each needs its Java_lpsolver_LpxNative_* twin."""
     java = open(os.path.join(ROOT, "jni", "java", "lpsolver", "LpxNative.java")).read()

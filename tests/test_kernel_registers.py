@@ -16,16 +16,27 @@ SRC = os.path.join(ROOT, "linear_programming_solver_amd", "csrc", "lpx_kernels.h
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.fixture(scope="module")
-def device_asm(tmp_path_factory):
+def _compile_asm(tmp_path_factory, fused):
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("asm") / "lpx_kernels.s"
-    # the flags of csrc/Makefile that matter for code generation
+    out = tmp_path_factory.mktemp("asm%d" % fused) / "lpx_kernels.s"
+    # the flags of csrc/Makefile that matter for code generation (the file is compiled twice: LPX_FUSED = 0 / 1)
     subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
-                           "-ffp-contract=off", "-Wno-unused-result", "-S", "--cuda-device-only", SRC, "-o", str(out)],
-                          stderr=subprocess.DEVNULL)
+                           "-ffp-contract=off", "-Wno-unused-result", "-DLPX_FUSED=%d" % fused, "-S", "--cuda-device-only",
+                           SRC, "-o", str(out)], stderr=subprocess.DEVNULL)
     return out.read_text()
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    """lpxk::plain — the default arithmetic (product and difference rounded separately)."""
+    return _compile_asm(tmp_path_factory, 0)
+
+
+@pytest.fixture(scope="module")
+def device_asm_fused(tmp_path_factory):
+    """lpxk::fused — the opt-in fused-arithmetic compilation of the same file."""
+    return _compile_asm(tmp_path_factory, 1)
 
 
 def _resources(asm, kernel):
@@ -140,7 +151,7 @@ def test_no_register_copy_reads_a_hand_issued_load_before_its_wait(device_asm, k
 
 
 # ---- round 3: the LDS-DMA sweep kernels -------------------------------------------------------------------------------
-@pytest.mark.parametrize("kernel", ["k_sweep32_dma", "k_sweep32_pull", "k_sweep64_pull"])
+@pytest.mark.parametrize("kernel", ["k_sweep32_dma", "k_sweep32_pull", "k_sweep64_pull", "k_sweep64_one"])
 def test_lds_dma_sweep_kernels_have_no_scratch(device_asm, kernel):
     """Their tableau loads land in LDS, not in registers, but the pivot-row slices (128 VGPRs) must stay in registers
     and two workgroups must fit a CU: no scratch, no AGPRs, at most 256 VGPRs, LDS <= 80 KiB."""
@@ -153,7 +164,7 @@ def test_lds_dma_sweep_kernels_have_no_scratch(device_asm, kernel):
     assert len(lds) == 4 and all(int(x) <= 80 * 1024 for x in lds), lds
 
 
-@pytest.mark.parametrize("kernel", ["k_sweep32_pull", "k_sweep64_pull"])
+@pytest.mark.parametrize("kernel", ["k_sweep32_pull", "k_sweep64_pull", "k_sweep64_one"])
 def test_pulled_tickets_are_not_touched_before_they_are_taken(device_asm, kernel):
     """The pull kernels' only hand-issued operation with a register destination is the ticket atomic.  Between the asm
     statement that issues it and the v_readfirstlane that takes the ticket (behind a hand-written s_waitcnt vmcnt and
@@ -193,3 +204,56 @@ def test_pulled_tickets_are_not_touched_before_they_are_taken(device_asm, kernel
                     taken = True
                     break
             assert taken, (name, reg)
+
+
+# ---- round 4 ---------------------------------------------------------------------------------------------------------
+def test_round4_decision_kernel_keeps_its_arrays_in_registers(device_asm, device_asm_fused):
+    """k_block_chain2_t<32, 256> (the default decision kernel of the one-device loop) in both compilations: one wave per
+    SIMD, its register arrays in VGPRs / AGPRs.  At most a few dozen bytes of scratch (one 16-byte pair spilled around
+    the rare full exchange at the end of a decision), nothing on the hand-off path: every scratch access sits behind the
+    last poll of workgroup 0's record."""
+    for asm in (device_asm, device_asm_fused):
+        res = {k: v for k, v in _resources(asm, "k_block_chain2_t").items() if "Li32E" in k}
+        assert len(res) == 1, sorted(res)
+        for name, r in res.items():
+            assert r["private_seg_size"] <= 64, (name, r)
+        for name, lines in _kernel_bodies(asm, "k_block_chain2_t").items():
+            if "Li32E" not in name:
+                continue
+            code = [ln for ln in lines if ln and not ln.startswith((";", "."))]
+            scratch = [k for k, ln in enumerate(code) if ln.startswith("scratch_")]
+            assert all(k > 0.85 * len(code) for k in scratch), (name, scratch, len(code))
+
+
+def _sweep_arith(asm, kernel):
+    """(v_fma_f64, v_mul_f64 + v_add_f64) instruction counts summed over the instantiations of a sweep kernel."""
+    fma = unfused = 0
+    for lines in _kernel_bodies(asm, kernel).values():
+        fma += sum(1 for ln in lines if ln.startswith("v_fma_f64"))
+        unfused += sum(1 for ln in lines if ln.startswith(("v_mul_f64", "v_add_f64")))
+    return fma, unfused
+
+
+@pytest.mark.parametrize("kernel", ["k_sweep32_pull", "k_sweep64_one", "k_update_tiles"])
+def test_the_two_compilations_differ_in_the_update_arithmetic_only(device_asm, device_asm_fused, kernel):
+    """lpxk::plain: every update is v_mul_f64 + v_add_f64 (two roundings, LPState.java:162) and no FMA is formed;
+    lpxk::fused: one v_fma_f64 per update and no separate multiply / add — same count of updates in both."""
+    pf, pu = _sweep_arith(device_asm, kernel)
+    ff, fu = _sweep_arith(device_asm_fused, kernel)
+    assert pf == 0 and pu > 0 and pu % 2 == 0, (kernel, pf, pu)
+    assert fu == 0 and ff == pu // 2, (kernel, ff, fu, pu)
+
+
+def test_mfma_sweep_fits_two_waves_per_simd(device_asm_fused):
+    """k_sweep64_mfma2 (fused blocks of 33..64 on the matrix cores): 64 MFMAs per tile in three unrolled tile slots, no
+    scratch, at most 256 registers in all (two waves per SIMD), 64 KiB of LDS for the B operands (two workgroups per CU);
+    the default compilation has no such kernel."""
+    res = _resources(device_asm_fused, "k_sweep64_mfma2")
+    assert len(res) == 4, sorted(res)
+    for name, r in res.items():
+        assert r["private_seg_size"] == 0 and r["num_vgpr"] + r["num_agpr"] <= 256, (name, r)
+    for name, lines in _kernel_bodies(device_asm_fused, "k_sweep64_mfma2").items():
+        assert sum(1 for ln in lines if ln.startswith("v_mfma_f64_16x16x4")) == 192, name
+    lds = re.findall(r"\.amdhsa_group_segment_fixed_size (\d+)", "".join(
+        device_asm_fused[m.start():m.start() + 4000] for m in re.finditer(r"\.amdhsa_kernel \S*k_sweep64_mfma2", device_asm_fused)))
+    assert len(lds) == 4 and all(int(x) <= 80 * 1024 for x in lds), lds
