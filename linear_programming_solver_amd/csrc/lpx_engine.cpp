@@ -559,8 +559,8 @@ static int build_block_ring(lpx_state* s) {
   // batches of 4 rows (1 KiB each)
   HIP_TRY(hipMalloc((void**)&s->R.tickets, (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128));
   HIP_TRY(hipMemsetAsync(s->R.tickets, 0, (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128, s->stream));
-  HIP_TRY(hipMalloc((void**)&s->R.clk, 64));
-  HIP_TRY(hipMemsetAsync(s->R.clk, 0, 64, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.clk, 256));
+  HIP_TRY(hipMemsetAsync(s->R.clk, 0, 256, s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.col_packed, (size_t)(mp / 4 + 1) * 2048));
   HIP_TRY(hipMemsetAsync(s->R.col_packed, 0, (size_t)(mp / 4 + 1) * 2048, s->stream));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
@@ -1004,11 +1004,23 @@ extern "C" int lpx_state_get_info(lpx_state* s, lpx_state_info* out) {
     s->info.sweep_xcd_mask = (int32_t)h[lpxk::kChainMaxWgs];
   }
   s->info.sweep_clock_mhz = 0;
-  if (s->R.clk) {   // shader clock over the last pulled sweep: s_memtime ticks per 100 MHz tick between the two probes
-    long long c4[4] = {0, 0, 0, 0};
+  if (s->R.clk) {   // shader clock over the last pulled sweep: s_memtime ticks per 100 MHz tick between the two probes,
+                    // XCD by XCD (the counter is per XCD), median over the XCDs that took both stamps
+    long long c32[32] = {};
     HIP_TRY(hipStreamSynchronize(s->stream));
-    HIP_TRY(hipMemcpy(c4, s->R.clk, sizeof c4, hipMemcpyDeviceToHost));
-    if (c4[3] > c4[1] && c4[2] > c4[0]) s->info.sweep_clock_mhz = (int32_t)(100.0 * (double)(c4[2] - c4[0]) / (double)(c4[3] - c4[1]) + 0.5);
+    HIP_TRY(hipMemcpy(c32, s->R.clk, sizeof c32, hipMemcpyDeviceToHost));
+    std::vector<double> mhz;
+    for (int x = 0; x < 8; x++) {
+      const long long* c4 = c32 + 4 * x;
+      if (c4[3] > c4[1] && c4[2] > c4[0] && c4[3] - c4[1] > 1000) {   // (> 10 us apart)
+        const double f = 100.0 * (double)(c4[2] - c4[0]) / (double)(c4[3] - c4[1]);
+        if (f > 300.0 && f < 3500.0) mhz.push_back(f);
+      }
+    }
+    if (!mhz.empty()) {
+      std::sort(mhz.begin(), mhz.end());
+      s->info.sweep_clock_mhz = (int32_t)(mhz[mhz.size() / 2] + 0.5);
+    }
   }
   *out = s->info;
   return 0;

@@ -82,7 +82,7 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   unsigned* census;        // [w] = XCC id + 1 of chain workgroup w; [kChainMaxWgs] = OR of (1 << XCC id) of sampled sweep workgroups
   double* col_packed;      // k_sweep32_pull: the block's multipliers as [batch of 4 rows][pivot][row]: (mp / 4) x 1 KiB (2 KiB for blocks of 64)
   unsigned* tickets;       // k_sweep32_pull: one batch counter per 128-column sub-strip, 128 bytes apart (ld / 128 of them)
-  long long* clk;          // clock probe of the last pulled sweep: {s_memtime, 100 MHz} in front of it, the same pair behind it
+  long long* clk;          // clock probe of the last pulled sweep, per XCD x: clk[4 x + 0..1] = {s_memtime, 100 MHz} in front of it, [4 x + 2..3] behind it
   const double* zeros;     // 256 bytes of +0.0: what k_sweep32_dma's multiplier DMA reads for the identity steps of a partly filled block
   // shards of an lpx_multi only (else NULL): written by the peers' decision kernels
   void* mg_mail;                   // MgMail[2][kMaxDevices]

@@ -2986,7 +2986,10 @@ __global__ __launch_bounds__(256) void k_pack_multipliers(const double* __restri
   const int np = ring_count(ring, KP, kmax, &sh_np);
   // clock probe (lpx_state_info.sweep_clock_mhz): shader-clock and 100 MHz stamps in front of the sweep; k_block_fixup
   // takes the matching pair behind it
-  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime(); clk[1] = wall_clock64(); }
+  if (clk && blockIdx.x < 64 && threadIdx.x == 0) {   // (s_memtime is a per-XCD counter: a pair of stamps per XCD)
+    const unsigned x = xcc_id() & 7u;
+    clk[x * 4 + 0] = __builtin_amdgcn_s_memtime(); clk[x * 4 + 1] = wall_clock64();
+  }
   // the sweep's ticket counters start at zero (one per sub-strip, 128 bytes apart): cleared here, in the launch in
   // front of the sweep, instead of by a memset launch of their own
   if (blockIdx.x == 0)
@@ -3546,7 +3549,10 @@ __global__ __launch_bounds__(256) void k_pack_multipliers_mfma(const double* __r
                                                                int nsub, long long* __restrict__ clk) {
   __shared__ int sh_np;
   const int np = ring_count(ring, 64, kmax, &sh_np);
-  if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime(); clk[1] = wall_clock64(); }
+  if (clk && blockIdx.x < 64 && threadIdx.x == 0) {   // (s_memtime is a per-XCD counter: a pair of stamps per XCD)
+    const unsigned x = xcc_id() & 7u;
+    clk[x * 4 + 0] = __builtin_amdgcn_s_memtime(); clk[x * 4 + 1] = wall_clock64();
+  }
   if (blockIdx.x == 0)
     for (int u = threadIdx.x; u < nsub; u += 256) tickets[u * 32] = 0u;
   // one workgroup per tile: thread = (pivot group pair, lane); reads along rows (i fastest): 128-byte segments
@@ -3940,8 +3946,9 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
                                                      const double* __restrict__ row0_ring, int64_t mp,
                                                      const LpxCtl* __restrict__ ring, int kmax,
                                                      const double* b_src, long long* __restrict__ clk) {
-  if (clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-    clk[2] = __builtin_amdgcn_s_memtime(); clk[3] = wall_clock64();
+  if (clk && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    const unsigned x = xcc_id() & 7u;
+    clk[x * 4 + 2] = __builtin_amdgcn_s_memtime(); clk[x * 4 + 3] = wall_clock64();
   }
   __shared__ double sh_p[kBlockMax], sh_bl[kBlockMax];
   __shared__ double sh_x[kBlockMax][kFixChunk];   // job 0: prow_r[e_s]; job 1: col_r[l_s]   (r: all pivots, s: this chunk's)
