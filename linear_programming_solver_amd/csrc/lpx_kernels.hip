@@ -3686,7 +3686,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A
                                                           const double* __restrict__ prow_ring,
                                                           const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
                                                           const double* __restrict__ colM,   // [tile][group][lane]
-                                                          unsigned* __restrict__ tickets) {
+                                                          unsigned* __restrict__ tickets, int a_mask) {
   constexpr int NG = 16, CT = 4;
   __shared__ __attribute__((aligned(16))) double sh_b[2 * NG * CT * 64];
   __shared__ int sh_np;
@@ -3731,10 +3731,18 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A
         const double* q = reinterpret_cast<const double*>(base + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
         c[ct][r] = NT ? __builtin_nontemporal_load(q) : *q;
       }
-    const double* const am = colM + (int64_t)t * 1024 + lane;
+    const double* const am = colM + (int64_t)(t & a_mask) * 1024 + lane;   // (a_mask = -1; 0: timing experiment only)
 #pragma unroll
     for (int g = 0; g < NG; ++g) a[g] = am[g * 64];
   };
+#ifndef LPX_MFMA_SB
+#define LPX_MFMA_SB 1   // 1: scheduling barriers between a tile's loads and the previous tile's arithmetic (diagnostic builds: 0)
+#endif
+#if LPX_MFMA_SB
+#define LPX_MFMA_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define LPX_MFMA_FENCE (void)0
+#endif
   auto work_tile = [&](int t, d4v (&c)[CT], const double (&a)[NG]) {
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -3763,27 +3771,28 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A
   while (t0 < ntiles) {
     const unsigned r3 = pull();
     if (t2 < ntiles) load_tile(t2, c2, a2);
-    __builtin_amdgcn_sched_barrier(0);
+    LPX_MFMA_FENCE;
     work_tile(t0, c0, a0);
-    __builtin_amdgcn_sched_barrier(0);
+    LPX_MFMA_FENCE;
     const int t3 = take(r3);
     if (t1 >= ntiles) break;
     const unsigned r4 = pull();
     if (t3 < ntiles) load_tile(t3, c0, a0);
-    __builtin_amdgcn_sched_barrier(0);
+    LPX_MFMA_FENCE;
     work_tile(t1, c1, a1);
-    __builtin_amdgcn_sched_barrier(0);
+    LPX_MFMA_FENCE;
     const int t4 = take(r4);
     if (t2 >= ntiles) break;
     const unsigned r5 = pull();
     if (t4 < ntiles) load_tile(t4, c1, a1);
-    __builtin_amdgcn_sched_barrier(0);
+    LPX_MFMA_FENCE;
     work_tile(t2, c2, a2);
-    __builtin_amdgcn_sched_barrier(0);
+    LPX_MFMA_FENCE;
     const int t5 = take(r5);
     t0 = t3; t1 = t4; t2 = t5;
   }
 }
+#undef LPX_MFMA_FENCE
 #endif  // LPX_FUSED
 
 // ---- 64 pivots per pass: two stages of 32 inside one workgroup ------------------------------------------------------
@@ -4406,7 +4415,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
     LPX_EACH_NT_OOP(LPX_PRE_MFMA64)
 #undef LPX_PRE_MFMA64
 #define LPX_PRE_MFMA642(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
+    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, -1);
     LPX_EACH_NT_OOP(LPX_PRE_MFMA642)
 #undef LPX_PRE_MFMA642
 #endif
@@ -4587,12 +4596,13 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
   hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, s, R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
                      R.tickets, nstrips_full * 8, R.clk);
   if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
+    static const int a_mask = getenv("LPX_SWEEP_DIAG") && atoi(getenv("LPX_SWEEP_DIAG")) == 1 ? 0 : -1;   // timing experiments only
     const int ng2 = nstrips_full * 4;
     const int G2 = std::max(1, std::min(ntiles, 2 * slots / std::max(1, ng2)));
     const dim3 grid2(ng2 * G2), block2(256);
 #define LPX_LAUNCH_MFMA642(NT_, OOP_)                                                                               \
     hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), grid2, block2, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                       nstrips_full, R.col_packed, R.tickets)
+                       nstrips_full, R.col_packed, R.tickets, a_mask)
     if (A_src) { if (nt) LPX_LAUNCH_MFMA642(true, true); else LPX_LAUNCH_MFMA642(false, true); }
     else { if (nt) LPX_LAUNCH_MFMA642(true, false); else LPX_LAUNCH_MFMA642(false, false); }
 #undef LPX_LAUNCH_MFMA642
