@@ -3678,6 +3678,9 @@ __global__ __launch_bounds__(256, 1) void k_sweep64_mfma(double* __restrict__ A,
 // 128-column group, its four waves to the two 64-column sub-strips in pairs, and the B operands of both sub-strips live
 // in LDS (2 x 32 KiB, [sub-strip][group][column tile][lane]: every MFMA's B is one conflict-free ds_read_b64 with an
 // immediate offset); the registers hold three tiles of C and A.  Two workgroups per CU.
+#ifndef LPX_MFMA_DIAG
+#define LPX_MFMA_DIAG 0   // timing experiments only (results wrong): 2 no stores, 4 no tile loads, 8 no MFMAs, 16 no A loads
+#endif
 constexpr int kMfma2LdsBytes = 2 * 16 * 4 * 64 * 8;
 static_assert(2 * kMfma2LdsBytes <= 160 * 1024, "two workgroups per CU");
 template <bool NT, bool OOP>
@@ -3729,11 +3732,12 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const double* q = reinterpret_cast<const double*>(base + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
-        c[ct][r] = NT ? __builtin_nontemporal_load(q) : *q;
+        if (LPX_MFMA_DIAG & 4) c[ct][r] = (double)(lane + r + ct + t);
+        else c[ct][r] = NT ? __builtin_nontemporal_load(q) : *q;
       }
     const double* const am = colM + (int64_t)(t & a_mask) * 1024 + lane;   // (a_mask = -1; 0: timing experiment only)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) a[g] = am[g * 64];
+    for (int g = 0; g < NG; ++g) a[g] = (LPX_MFMA_DIAG & 16) ? (double)(lane + g + t) : am[g * 64];
   };
 #ifndef LPX_MFMA_SB
 #define LPX_MFMA_SB 1   // 1: scheduling barriers between a tile's loads and the previous tile's arithmetic (diagnostic builds: 0)
@@ -3747,9 +3751,15 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-        c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bl[(g * CT + ct) * 64], c[ct], 0, 0, 0);
+      for (int ct = 0; ct < CT; ++ct) {
+        if (LPX_MFMA_DIAG & 8) { if (g == 0) c[ct][0] += a[ct] + a[ct + 4] + a[ct + 8] + a[ct + 12]; }
+        else c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bl[(g * CT + ct) * 64], c[ct], 0, 0, 0);
+      }
     char* const out = dst_base + (int64_t)t * 16 * row_bytes;
+    if (LPX_MFMA_DIAG & 2) {   // one store per tile keeps the arithmetic alive
+      if (lane == 0) *reinterpret_cast<double*>(out) = c[0][0] + c[1][1] + c[2][2] + c[3][3] + c[0][3] + c[1][2] + c[2][1] + c[3][0] + c[0][1] + c[1][0] + c[2][3] + c[3][2] + c[0][2] + c[1][3] + c[2][0] + c[3][1];
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll

@@ -904,6 +904,15 @@ def test_cfg3_one_pass_form_30_pivots_vs_fp64_oracle(lps, oracle):
     assert info["block"] == 1 and info["nontemporal"] == 1
 
 
+@pytest.mark.parametrize("block", [1, 2])
+def test_cfg4_onepass_forms_12_pivots_vs_fp64_oracle(lps, oracle, block):
+    """The kernels behind bench.py's `onepass` object at the HEIGHT it times them at (32768 rows x 16384 columns, 4 GiB:
+    k_update<1, nt> = one pass per pivot, the reference's own schedule, LPState.java:150-181; k_update_tiles<2> = two
+    pivots per pass) against the oracle of the arithmetic mode, bit for bit."""
+    info = _timed_form_vs_oracle(lps, oracle, 32768, 16384, (12,), options={"block": block})
+    assert info["block"] == block and info["nontemporal"] == 1
+
+
 @pytest.mark.parametrize("form,name", [(0, "k_sweep32_pull"), (1, "k_sweep32_steady"), (2, "k_sweep32_dma")])
 def test_cfg3_sweep_forms_vs_fp64_oracle(lps, oracle, form, name):
     """The three steady-state sweep kernels of blocks of 17..32 pivots (round 3: LDS-DMA staging with batches pulled in
