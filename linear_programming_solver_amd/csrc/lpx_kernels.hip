@@ -3543,10 +3543,12 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_one(double* __restrict__ A, 
 typedef double d4v __attribute__((ext_vector_type(4)));
 
 // A operands of the MFMA sweep: colM[(tile * 16 + g) * 64 + 16 k + i] = -col_ring[4 g + k][16 tile + i]
+// (pairs != 0, k_sweep64_mfma2: groups 2 p and 2 p + 1 interleaved per lane, colM[(tile * 8 + p) * 128 + 2 lane + (g & 1)], so that
+// one 16-byte load per lane brings the A operands of two groups)
 __global__ __launch_bounds__(256) void k_pack_multipliers_mfma(const double* __restrict__ col_ring, int64_t mp,
                                                                const LpxCtl* __restrict__ ring, int kmax, int ntiles,
                                                                double* __restrict__ colM, unsigned* __restrict__ tickets,
-                                                               int nsub, long long* __restrict__ clk) {
+                                                               int nsub, long long* __restrict__ clk, int pairs) {
   __shared__ int sh_np;
   const int np = ring_count(ring, 64, kmax, &sh_np);
   if (clk && blockIdx.x < 64 && threadIdx.x == 0) {   // (s_memtime is a per-XCD counter: a pair of stamps per XCD)
@@ -3564,7 +3566,7 @@ __global__ __launch_bounds__(256) void k_pack_multipliers_mfma(const double* __r
     const int g = idx >> 6, l = idx & 63, k = l >> 4, i = l & 15;
     const int s = 4 * g + k;
     const double c = s < np ? col_ring[(int64_t)s * mp + (int64_t)tile * 16 + i] : 0.0;
-    colM[(int64_t)tile * 1024 + idx] = -c;
+    colM[(int64_t)tile * 1024 + (pairs ? (g >> 1) * 128 + 2 * l + (g & 1) : idx)] = -c;
   }
 }
 
@@ -3678,19 +3680,36 @@ __global__ __launch_bounds__(256, 1) void k_sweep64_mfma(double* __restrict__ A,
 // 128-column group, its four waves to the two 64-column sub-strips in pairs, and the B operands of both sub-strips live
 // in LDS (2 x 32 KiB, [sub-strip][group][column tile][lane]: every MFMA's B is one conflict-free ds_read_b64 with an
 // immediate offset); the registers hold three tiles of C and A.  Two workgroups per CU.
+// Memory side (second version; the first one lost a third of its time here, profiles/r04_sweep64_mfma2_what_bounds.txt):
+//  * buffer addressing — the tile's base in the resource descriptor (SALU), the row group 4 r in the scalar offset, the
+//    lane part in ONE 32-bit VGPR, the column tile in the immediate: no per-load 64-bit VALU address, 30 fewer VGPRs;
+//  * the ticket is a hand-issued atomic (ticket_pull) taken behind `s_waitcnt vmcnt(48)` = the 32 loads and 16 stores
+//    issued after it.  (`if (lane == 0) atomicAdd` compiled to an aggregated atomic followed by `s_waitcnt vmcnt(0)`:
+//    every tile drained the wave's whole queue, stores included.)  The compiler does not know of the atomic, so its own
+//    counts are one too strict, never too lax;
+//  * the loop body is straight-line: the tile of a ticket past the end is CLAMPED to the last tile for its loads (a
+//    re-read, two per wave) and the loop is left before its arithmetic, so no conditional load makes the compiler's
+//    vmcnt bookkeeping fall back to draining counts.
 #ifndef LPX_MFMA_DIAG
 #define LPX_MFMA_DIAG 0   // timing experiments only (results wrong): 2 no stores, 4 no tile loads, 8 no MFMAs, 16 no A loads
 #endif
 constexpr int kMfma2LdsBytes = 2 * 16 * 4 * 64 * 8;
 static_assert(2 * kMfma2LdsBytes <= 160 * 1024, "two workgroups per CU");
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+#ifndef LPX_MFMA_SHAPE
+#define LPX_MFMA_SHAPE 0   // copy-shape experiments of the diagnostic builds (1: 4 rows x 256 B per instruction, 2: 2 x 512 B, 3: 1 x 512 B)
+#endif
 template <bool NT, bool OOP>
-__global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A, const double* __restrict__ Asrc,
+__global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const double* Asrc,   // (no __restrict__: see below)
                                                           int64_t ld, int m_local,
                                                           const double* __restrict__ prow_ring,
                                                           const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
-                                                          const double* __restrict__ colM,   // [tile][group][lane]
-                                                          unsigned* __restrict__ tickets, int a_mask) {
+                                                          const double* colM,   // [tile][group][lane]
+                                                          unsigned* tickets, int a_mask) {
   constexpr int NG = 16, CT = 4;
+  constexpr int kRsrcWord3 = 0x00020000;           // raw buffer, 32-bit data format (gfx9 family)
+  constexpr int kAuxNt = NT ? 2 : 0;               // cache policy bit 1 = nt
   __shared__ __attribute__((aligned(16))) double sh_b[2 * NG * CT * 64];
   __shared__ int sh_np;
   const int np = ring_count(ring, 64, kmax, &sh_np);
@@ -3701,43 +3720,64 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A
   const int grp = (ngroups % 8 == 0)
                       ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(ngroups / 8)) % (unsigned)ngroups)
                       : (int)(blockIdx.x % (unsigned)ngroups);
-  const int half = wave >> 1;                      // which of the group's two sub-strips this wave works on
-  const int sub = grp * 2 + half;
-  const int ntiles = m_local / 16;
-  unsigned* const ctr = tickets + sub * 32;
+  // ONE ticket counter per 128-column group: ticket T = (16-row block T / 2, 64-column half T % 2), so the two halves of
+  // a row's 1 KiB (one DRAM page) are pulled back to back by two waves (second version; with a counter per half the
+  // halves of a page were fetched at unrelated times: 5.3 TB/s alone where k_sweep32_pull's 1 KiB segments stream at 6)
+  const int ntiles = 2 * (m_local / 16);
+  unsigned* const ctr = tickets + grp * 32;
   const int64_t row_bytes = ld * 8;
-  char* const dst_base = reinterpret_cast<char*>(A + sub * 64);
-  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + sub * 64) : dst_base;
-  const uint32_t rb32 = (uint32_t)row_bytes;
-  const uint32_t off_c = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 8u;
-  // the B operands of the wave's sub-strip into LDS: the pair of waves shares the 64 (group, column tile) images
-  double* const myb = sh_b + half * (NG * CT * 64);
-  for (int q = (wave & 1); q < NG * CT; q += 2) {
-    const int g = q / CT, ct = q % CT;
+  char* const dst_base = reinterpret_cast<char*>(A + grp * 128);
+  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + grp * 128) : dst_base;
+  const uint32_t rb32 = (uint32_t)row_bytes;       // 16 rows x ld x 8 < 2^32 (launcher)
+  const uint32_t off_c = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 8u;   // row lane / 16, column lane % 16
+  const uint32_t off_a = (uint32_t)lane * 8u;
+  // the B operands of the group's two halves into LDS: the four waves share the 128 (half, group, column tile) images
+  for (int q = wave; q < 2 * NG * CT; q += 4) {
+    const int h = q / (NG * CT), g = (q / CT) % NG, ct = q % CT;
     const int s = 4 * g + (lane >> 4);
-    myb[q * 64 + lane] = s < np ? prow_ring[(int64_t)s * ld + sub * 64 + ct * 16 + (lane & 15)] : 0.0;
+    sh_b[q * 64 + lane] = s < np ? prow_ring[(int64_t)s * ld + grp * 128 + h * 64 + ct * 16 + (lane & 15)] : 0.0;
   }
   __syncthreads();
-  const double* const bl = myb + lane;
-  auto pull = [&]() -> unsigned {
-    unsigned t = 0;
-    if (lane == 0) t = atomicAdd(ctr, 1u);
-    return t;
-  };
-  auto take = [&](unsigned raw) -> int { return __builtin_amdgcn_readfirstlane((int)raw); };
   auto load_tile = [&](int t, d4v (&c)[CT], double (&a)[NG]) {
-    const char* const base = src_base + (int64_t)t * 16 * row_bytes;   // uniform
+    const int tt = min(t, ntiles - 1);                                  // uniform; past the end: the last tile again
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(src_base) + (int64_t)(tt >> 1) * 16 * row_bytes + (tt & 1) * 512, 0, -1, kRsrcWord3);
+#if LPX_MFMA_SHAPE == 0
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const double* q = reinterpret_cast<const double*>(base + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
         if (LPX_MFMA_DIAG & 4) c[ct][r] = (double)(lane + r + ct + t);
-        else c[ct][r] = NT ? __builtin_nontemporal_load(q) : *q;
+        else c[ct][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, off_c + (uint32_t)ct * 128u,
+                                                                                         (int)((uint32_t)(4 * r) * rb32), kAuxNt));
       }
-    const double* const am = colM + (int64_t)(t & a_mask) * 1024 + lane;   // (a_mask = -1; 0: timing experiment only)
+#else   // copy-shape experiments (with LPX_MFMA_DIAG = 24 only: the register layout is not the MFMA's)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) a[g] = (LPX_MFMA_DIAG & 16) ? (double)(lane + g + t) : am[g * 64];
+    for (int i = 0; i < (LPX_MFMA_SHAPE == 3 ? 16 : 8); ++i) {
+      if (LPX_MFMA_SHAPE == 1) {        // 4 rows x 256 B per instruction
+        const uint32_t vo = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 16u + (uint32_t)(i & 1) * 256u;
+        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rc, vo, (int)((uint32_t)(4 * (i >> 1)) * rb32), kAuxNt);
+        c[2 * (i & 1)][i >> 1] = __builtin_bit_cast(double, v2u{x[0], x[1]});
+        c[2 * (i & 1) + 1][i >> 1] = __builtin_bit_cast(double, v2u{x[2], x[3]});
+      } else if (LPX_MFMA_SHAPE == 2) { // 2 rows x 512 B per instruction
+        const uint32_t vo = (uint32_t)(lane >> 5) * rb32 + (uint32_t)(lane & 31) * 16u;
+        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rc, vo, (int)((uint32_t)(2 * i) * rb32), kAuxNt);
+        c[2 * (i & 1)][i >> 1] = __builtin_bit_cast(double, v2u{x[0], x[1]});
+        c[2 * (i & 1) + 1][i >> 1] = __builtin_bit_cast(double, v2u{x[2], x[3]});
+      } else {                          // 1 row x 512 B per instruction (dwordx2)
+        c[i & 3][i >> 2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, off_a, (int)((uint32_t)i * rb32), kAuxNt));
+      }
+    }
+#endif
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double*>(colM) + (int64_t)((tt >> 1) & a_mask) * 1024, 0, -1, kRsrcWord3);   // (a_mask = -1; 0: timing experiment only)
+#pragma unroll
+    for (int p = 0; p < NG / 2; ++p) {   // (k_pack_multipliers_mfma, pairs: the A operands of groups 2 p and 2 p + 1 side by side)
+      if (LPX_MFMA_DIAG & 16) { a[2 * p] = (double)(lane + p + t); a[2 * p + 1] = (double)(lane - p + t); continue; }
+      const v4u x = __builtin_amdgcn_raw_buffer_load_b128(ra, 2u * off_a + (uint32_t)(p & 3) * 1024u, (p >> 2) * 4096, 0);
+      a[2 * p] = __builtin_bit_cast(double, v2u{x[0], x[1]});
+      a[2 * p + 1] = __builtin_bit_cast(double, v2u{x[2], x[3]});
+    }
   };
 #ifndef LPX_MFMA_SB
 #define LPX_MFMA_SB 1   // 1: scheduling barriers between a tile's loads and the previous tile's arithmetic (diagnostic builds: 0)
@@ -3748,6 +3788,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A
 #define LPX_MFMA_FENCE (void)0
 #endif
   auto work_tile = [&](int t, d4v (&c)[CT], const double (&a)[NG]) {
+    const double* const bl = sh_b + (min(t, ntiles - 1) & 1) * (NG * CT * 64) + lane;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -3755,52 +3796,89 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* __restrict__ A
         if (LPX_MFMA_DIAG & 8) { if (g == 0) c[ct][0] += a[ct] + a[ct + 4] + a[ct + 8] + a[ct + 12]; }
         else c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bl[(g * CT + ct) * 64], c[ct], 0, 0, 0);
       }
-    char* const out = dst_base + (int64_t)t * 16 * row_bytes;
+    // a ticket past the end: the arithmetic runs on the re-read last tile and the stores are DROPPED by the buffer's range
+    // check (num_records 0), so the loop body has no exit but its back edge
+    const int tt = min(t, ntiles - 1);
+    char* const out = dst_base + (int64_t)(tt >> 1) * 16 * row_bytes + (tt & 1) * 512;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(out, 0, __builtin_amdgcn_readfirstlane(t < ntiles ? -1 : 0), kRsrcWord3);
     if (LPX_MFMA_DIAG & 2) {   // one store per tile keeps the arithmetic alive
       if (lane == 0) *reinterpret_cast<double*>(out) = c[0][0] + c[1][1] + c[2][2] + c[3][3] + c[0][3] + c[1][2] + c[2][1] + c[3][0] + c[0][1] + c[1][0] + c[2][3] + c[3][2] + c[0][2] + c[1][3] + c[2][0] + c[3][1];
       return;
     }
+#if LPX_MFMA_SHAPE == 0
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        double* q = reinterpret_cast<double*>(out + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
-        if (NT) __builtin_nontemporal_store(c[ct][r], q); else *q = c[ct][r];
+      for (int ct = 0; ct < CT; ++ct)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (double)c[ct][r]), rd, off_c + (uint32_t)ct * 128u,
+                                              (int)((uint32_t)(4 * r) * rb32), kAuxNt);
+#else
+#pragma unroll
+    for (int i = 0; i < (LPX_MFMA_SHAPE == 3 ? 16 : 8); ++i) {
+      if (LPX_MFMA_SHAPE == 3) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (double)c[i & 3][i >> 2]), rd, off_a, (int)((uint32_t)i * rb32), kAuxNt);
+      } else {
+        const v2u lo = __builtin_bit_cast(v2u, (double)c[2 * (i & 1)][i >> 1]), hi = __builtin_bit_cast(v2u, (double)c[2 * (i & 1) + 1][i >> 1]);
+        const v4u x = {lo[0], lo[1], hi[0], hi[1]};
+        if (LPX_MFMA_SHAPE == 1)
+          __builtin_amdgcn_raw_buffer_store_b128(x, rd, (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 16u + (uint32_t)(i & 1) * 256u,
+                                                 (int)((uint32_t)(4 * (i >> 1)) * rb32), kAuxNt);
+        else
+          __builtin_amdgcn_raw_buffer_store_b128(x, rd, (uint32_t)(lane >> 5) * rb32 + (uint32_t)(lane & 31) * 16u, (int)((uint32_t)(2 * i) * rb32), kAuxNt);
       }
+    }
+#endif
+  };
+  // A ticket is pulled a whole step before it is taken (in front of the previous step's loads, taken behind this step's
+  // stores): two steps' loads and stores (81 operations) are younger than the atomic by then, more than the 63 the counter
+  // can hold, so the ticket has returned and the wait costs nothing.  (Taken behind the same step's stores, first version,
+  // every step ended by waiting for the loads and stores it had just issued — vmcnt counts in order.)
+  auto take = [&](unsigned& tk) -> int {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LPX_MFMA_DIAG || LPX_MFMA_SHAPE) ? 0 : 63) : "memory");
+    return ticket_take(tk);
   };
   d4v c0[CT], c1[CT], c2[CT];
   double a0[NG], a1[NG], a2[NG];
   int t0, t1, t2;
+  unsigned k0, k1, k2;                  // three ticket registers, rotating with the tile buffers
   {
-    const unsigned r0 = pull(), r1 = pull(), r2 = pull();
-    t0 = take(r0); t1 = take(r1); t2 = take(r2);
+    ticket_pull(k0, ctr); ticket_pull(k1, ctr); ticket_pull(k2, ctr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t0 = ticket_take(k0); t1 = ticket_take(k1); t2 = ticket_take(k2);
   }
-  if (t0 < ntiles) load_tile(t0, c0, a0);
-  if (t1 < ntiles) load_tile(t1, c1, a1);
+  if (t0 >= ntiles) return;
+  load_tile(t0, c0, a0);
+  load_tile(t1, c1, a1);
+  // The loop is entered with nothing in flight (once per wave): the compiler's vmcnt bookkeeping at the loop head is
+  // then the loop-carried state alone — merged with the prologue's tiles in flight it waited in the first step of EVERY
+  // round for loads the previous step had just issued.  (A real s_waitcnt, which the compiler's pass reads.)
+  ticket_pull(k0, ctr);                 // the ticket taken at the end of the loop's first step (covered by the wait below)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched
+  // Straight-line body, ONE exit at the back edge.  (With `break`s between the steps the compiler folds the exits into
+  // one latch block, and its vmcnt bookkeeping then sees paths that skip a step: it waited for the loads the previous
+  // step had just issued.)  Tickets only grow, t0 < t1 < t2: once t0 is past the end everything later is.
 #pragma unroll 1
-  while (t0 < ntiles) {
-    const unsigned r3 = pull();
-    if (t2 < ntiles) load_tile(t2, c2, a2);
+  do {
+    ticket_pull(k1, ctr);
+    load_tile(t2, c2, a2);
     LPX_MFMA_FENCE;
     work_tile(t0, c0, a0);
     LPX_MFMA_FENCE;
-    const int t3 = take(r3);
-    if (t1 >= ntiles) break;
-    const unsigned r4 = pull();
-    if (t3 < ntiles) load_tile(t3, c0, a0);
+    const int t3 = take(k0);
+    ticket_pull(k2, ctr);
+    load_tile(t3, c0, a0);
     LPX_MFMA_FENCE;
     work_tile(t1, c1, a1);
     LPX_MFMA_FENCE;
-    const int t4 = take(r4);
-    if (t2 >= ntiles) break;
-    const unsigned r5 = pull();
-    if (t4 < ntiles) load_tile(t4, c1, a1);
+    const int t4 = take(k1);
+    ticket_pull(k0, ctr);
+    load_tile(t4, c1, a1);
     LPX_MFMA_FENCE;
     work_tile(t2, c2, a2);
     LPX_MFMA_FENCE;
-    const int t5 = take(r5);
+    const int t5 = take(k2);
     t0 = t3; t1 = t4; t2 = t5;
-  }
+  } while (t0 < ntiles);
 }
 #undef LPX_MFMA_FENCE
 #endif  // LPX_FUSED
@@ -4419,7 +4497,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
     LPX_EACH_NT_OOP(LPX_PRE_ONE64)
 #undef LPX_PRE_ONE64
 #if LPX_FUSED
-    hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr);
+    hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr, 0);
 #define LPX_PRE_MFMA64(NT_, OOP_) \
     hipLaunchKernelGGL((k_sweep64_mfma<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
     LPX_EACH_NT_OOP(LPX_PRE_MFMA64)
@@ -4604,7 +4682,7 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
   const int ntiles = m_local / 16;
   const int G = std::max(1, std::min(ntiles, slots / std::max(1, ngroups)));
   hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, s, R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
-                     R.tickets, nstrips_full * 8, R.clk);
+                     R.tickets, nstrips_full * 8, R.clk, two_waves ? 1 : 0);
   if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
     static const int a_mask = getenv("LPX_SWEEP_DIAG") && atoi(getenv("LPX_SWEEP_DIAG")) == 1 ? 0 : -1;   // timing experiments only
     const int ng2 = nstrips_full * 4;

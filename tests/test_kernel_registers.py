@@ -257,3 +257,27 @@ def test_mfma_sweep_fits_two_waves_per_simd(device_asm_fused):
     lds = re.findall(r"\.amdhsa_group_segment_fixed_size (\d+)", "".join(
         device_asm_fused[m.start():m.start() + 4000] for m in re.finditer(r"\.amdhsa_kernel \S*k_sweep64_mfma2", device_asm_fused)))
     assert len(lds) == 4 and all(int(x) <= 80 * 1024 for x in lds), lds
+
+
+def test_mfma_sweep_loop_never_drains_its_memory_queue(device_asm_fused):
+    """The memory side of k_sweep64_mfma2's loop as designed: buffer addressing (no 64-bit VALU address
+    per load), a straight-line body with ONE backward branch, three hand-issued ticket atomics per round and, between
+    the loop head and that branch, no vmcnt wait that could stall on anything younger than two steps (>= 62: the
+    compiler's clamped counts and the no-cost wait in front of a ticket).  The first version had `vmcnt(0)` behind every
+    aggregated atomic and, with exits between the steps, waits for the loads the previous step had just issued."""
+    for name, lines in _kernel_bodies(device_asm_fused, "k_sweep64_mfma2").items():
+        back = [k for k, ln in enumerate(lines) if re.match(r"s_cbranch_scc[01] \.LBB\d+_\d+", ln)]
+        labels = {m.group(1): k for k, ln in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", ln)] if m}
+        loops = [(labels[ln.split()[-1]], k) for k in back for ln in [lines[k]] if labels.get(ln.split()[-1], k) < k]
+        assert loops, name
+        head, tail = max(loops, key=lambda ht: ht[1] - ht[0])     # the loop with the longest body: the tile loop
+        body = lines[head:tail]
+        assert sum(1 for ln in body if ln.startswith("v_mfma_f64_16x16x4")) == 192, name
+        assert sum(1 for ln in body if ln.startswith("global_atomic_add")) == 3, name
+        assert not any(ln.startswith(("s_cbranch", "s_branch")) for ln in body), name
+        assert sum(1 for ln in body if ln.startswith("buffer_load_dwordx2")) == 48, name      # three tiles of C
+        assert sum(1 for ln in body if ln.startswith("buffer_load_dwordx4")) == 24, name      # three tiles of A operands
+        assert sum(1 for ln in body if ln.startswith("buffer_store_dwordx2")) == 48, name
+        assert not any(ln.startswith(("global_load", "global_store", "flat_", "v_lshl_add_u64")) for ln in body), name
+        waits = [int(x) for ln in body for x in re.findall(r"vmcnt\((\d+)\)", ln)]
+        assert waits and min(waits) >= 62, (name, sorted(set(waits)))
