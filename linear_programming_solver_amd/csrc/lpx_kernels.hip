@@ -3779,6 +3779,9 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
       a[2 * p + 1] = __builtin_bit_cast(double, v2u{x[2], x[3]});
     }
   };
+#ifndef LPX_MFMA_BPIPE
+#define LPX_MFMA_BPIPE 1
+#endif
 #ifndef LPX_MFMA_SB
 #define LPX_MFMA_SB 1   // 1: scheduling barriers between a tile's loads and the previous tile's arithmetic (diagnostic builds: 0)
 #endif
@@ -3796,6 +3799,14 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
         if (LPX_MFMA_DIAG & 8) { if (g == 0) c[ct][0] += a[ct] + a[ct + 4] + a[ct + 8] + a[ct + 12]; }
         else c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bl[(g * CT + ct) * 64], c[ct], 0, 0, 0);
       }
+#if LPX_MFMA_BPIPE   // the B operands of group g + 1 (two ds_read2st64_b64) are asked for in front of group g's four MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+#endif
     // a ticket past the end: the arithmetic runs on the re-read last tile and the stores are DROPPED by the buffer's range
     // check (num_records 0), so the loop body has no exit but its back edge
     const int tt = min(t, ntiles - 1);
