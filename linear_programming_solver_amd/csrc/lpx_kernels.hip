@@ -3739,7 +3739,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
   }
   __syncthreads();
   auto load_tile = [&](int t, d4v (&c)[CT], double (&a)[NG]) {
-    const int tt = min(t, ntiles - 1);                                  // uniform; past the end: the last tile again
+    const int tt = max(0, min(t, ntiles - 1));                          // uniform; past the end: the last tile again
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(src_base) + (int64_t)(tt >> 1) * 16 * row_bytes + (tt & 1) * 512, 0, -1, kRsrcWord3);
 #if LPX_MFMA_SHAPE == 0
@@ -3791,7 +3791,7 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
 #define LPX_MFMA_FENCE (void)0
 #endif
   auto work_tile = [&](int t, d4v (&c)[CT], const double (&a)[NG]) {
-    const double* const bl = sh_b + (min(t, ntiles - 1) & 1) * (NG * CT * 64) + lane;
+    const double* const bl = sh_b + (max(0, min(t, ntiles - 1)) & 1) * (NG * CT * 64) + lane;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -3809,9 +3809,9 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
 #endif
     // a ticket past the end: the arithmetic runs on the re-read last tile and the stores are DROPPED by the buffer's range
     // check (num_records 0), so the loop body has no exit but its back edge
-    const int tt = min(t, ntiles - 1);
+    const int tt = max(0, min(t, ntiles - 1));
     char* const out = dst_base + (int64_t)(tt >> 1) * 16 * row_bytes + (tt & 1) * 512;
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(out, 0, __builtin_amdgcn_readfirstlane(t < ntiles ? -1 : 0), kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(out, 0, __builtin_amdgcn_readfirstlane((unsigned)t < (unsigned)ntiles ? -1 : 0), kRsrcWord3);
     if (LPX_MFMA_DIAG & 2) {   // one store per tile keeps the arithmetic alive
       if (lane == 0) *reinterpret_cast<double*>(out) = c[0][0] + c[1][1] + c[2][2] + c[3][3] + c[0][3] + c[1][2] + c[2][1] + c[3][0] + c[0][1] + c[1][0] + c[2][3] + c[3][2] + c[0][2] + c[1][3] + c[2][0] + c[3][1];
       return;
@@ -3840,55 +3840,59 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
     }
 #endif
   };
-  // A ticket is pulled a whole step before it is taken (in front of the previous step's loads, taken behind this step's
-  // stores): two steps' loads and stores (81 operations) are younger than the atomic by then, more than the 63 the counter
-  // can hold, so the ticket has returned and the wait costs nothing.  (Taken behind the same step's stores, first version,
-  // every step ended by waiting for the loads and stores it had just issued — vmcnt counts in order.)
+  // A ticket is pulled a whole step before it is taken: pulled in front of step i - 1's loads, taken in front of step i's.
+  // vmcnt counts in order, so the wait in front of the take covers exactly what is OLDER than step i - 1's loads, stores and
+  // step i's pull (41 operations) — operations that have had a step's arithmetic to complete and that step i's MFMAs need
+  // anyway.  (Taken behind the same step's stores, first version, every step ended by waiting for the loads and stores it
+  // had just issued.)
+  constexpr int kTileOps = LPX_MFMA_SHAPE == 0 || LPX_MFMA_SHAPE == 3 ? 16 : 8;
+  constexpr int kStepOps = ((LPX_MFMA_DIAG & 4) ? 0 : kTileOps) + ((LPX_MFMA_DIAG & 16) ? 0 : 8) + ((LPX_MFMA_DIAG & 2) ? 0 : kTileOps);
+  static_assert(kStepOps + 1 <= 63, "vmcnt is six bits wide");
   auto take = [&](unsigned& tk) -> int {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((LPX_MFMA_DIAG || LPX_MFMA_SHAPE) ? 0 : 63) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kStepOps + 1) : "memory");
     return ticket_take(tk);
   };
   d4v c0[CT], c1[CT], c2[CT];
   double a0[NG], a1[NG], a2[NG];
-  int t0, t1, t2;
+  int t0, t1;
   unsigned k0, k1, k2;                  // three ticket registers, rotating with the tile buffers
   {
-    ticket_pull(k0, ctr); ticket_pull(k1, ctr); ticket_pull(k2, ctr);
+    ticket_pull(k0, ctr); ticket_pull(k1, ctr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    t0 = ticket_take(k0); t1 = ticket_take(k1); t2 = ticket_take(k2);
+    t0 = ticket_take(k0); t1 = ticket_take(k1);
   }
   if (t0 >= ntiles) return;
   load_tile(t0, c0, a0);
   load_tile(t1, c1, a1);
+  ticket_pull(k2, ctr);                 // the ticket of the tile the loop's first step loads (covered by the wait below)
   // The loop is entered with nothing in flight (once per wave): the compiler's vmcnt bookkeeping at the loop head is
   // then the loop-carried state alone — merged with the prologue's tiles in flight it waited in the first step of EVERY
   // round for loads the previous step had just issued.  (A real s_waitcnt, which the compiler's pass reads.)
-  ticket_pull(k0, ctr);                 // the ticket taken at the end of the loop's first step (covered by the wait below)
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt untouched
   // Straight-line body, ONE exit at the back edge.  (With `break`s between the steps the compiler folds the exits into
   // one latch block, and its vmcnt bookkeeping then sees paths that skip a step: it waited for the loads the previous
-  // step had just issued.)  Tickets only grow, t0 < t1 < t2: once t0 is past the end everything later is.
+  // step had just issued.)  Tickets only grow, t0 < t1 < ...: once t0 is past the end everything later is.
 #pragma unroll 1
   do {
-    ticket_pull(k1, ctr);
+    ticket_pull(k0, ctr);
+    const int t2 = take(k2);
     load_tile(t2, c2, a2);
     LPX_MFMA_FENCE;
     work_tile(t0, c0, a0);
     LPX_MFMA_FENCE;
+    ticket_pull(k1, ctr);
     const int t3 = take(k0);
-    ticket_pull(k2, ctr);
     load_tile(t3, c0, a0);
     LPX_MFMA_FENCE;
     work_tile(t1, c1, a1);
     LPX_MFMA_FENCE;
+    ticket_pull(k2, ctr);
     const int t4 = take(k1);
-    ticket_pull(k0, ctr);
     load_tile(t4, c1, a1);
     LPX_MFMA_FENCE;
     work_tile(t2, c2, a2);
     LPX_MFMA_FENCE;
-    const int t5 = take(k2);
-    t0 = t3; t1 = t4; t2 = t5;
+    t0 = t3; t1 = t4;
   } while (t0 < ntiles);
 }
 #undef LPX_MFMA_FENCE
