@@ -1204,6 +1204,29 @@ def test_pulled_sweep_kernels_on_ragged_shapes(lps, oracle, shape, block, form, 
     st.close()
 
 
+@pytest.mark.parametrize("overlap,nt", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_blocks_of_64_in_place_and_out_of_place_with_and_without_nt(lps, oracle, arith, overlap, nt):
+    """The four instantiations of the sweep of a block of 64 (in place in the serial loop, out of place beside the
+    decisions; with and without the non-temporal hints) on a tableau with more tickets than workers, a partial last
+    strip and a partly filled last block: in the fused mode k_sweep64_mfma2, whose tickets past the end re-read the
+    last tile and have their stores dropped by the buffer range check — in place that tile may be rewritten by its
+    owner meanwhile."""
+    m, n = 4096, 5000
+    A, b, c = dense_lp(m, n, seed=4242)
+    st = lps.LPState(A, b, c, block=64, options={"overlap": overlap, "nt": nt})
+    ref = oracle.State(A, b, c, kind=oracle.FP64)
+    for budget in (64, 150, 40):
+        status, pivots, _ = st.simplex_loop(max_pivots=budget)
+        want = ref.simplex_loop(max_pivots=budget, threads=8)
+        assert (status, pivots) == (want["status"], want["pivots"]), (overlap, nt, budget)
+        assert_state_bits_equal(st.read(), ref.read(), "overlap %d nt %d budget %d" % (overlap, nt, budget))
+    info = st.info()
+    assert info["nontemporal"] == nt and info["block"] == 64, info
+    if arith == "fused":
+        assert info["sweep_kernel_name"] == "k_sweep64_mfma2", info
+    st.close()
+
+
 @pytest.mark.parametrize("shape", [(1024, 2112), (2048, 4100), (4096, 1024), (16, 512)])
 @pytest.mark.parametrize("form", [0, 4])
 @pytest.mark.parametrize("block", [40, 64])
