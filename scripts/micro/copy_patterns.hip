@@ -144,6 +144,43 @@ __global__ __launch_bounds__(256) void k_pull_wave(const double* __restrict__ sr
   }
 }
 
+// independent waves with tiles of R rows: a wave bound to a sub-strip of W8 bytes per row (1024 = 128 columns, one 16-byte
+// access per lane; 512 = 64 columns, one 8-byte access per lane — k_sweep64_mfma2's tile is 16 rows x 512 bytes)
+template <int R, int W8>
+__global__ __launch_bounds__(256) void k_pull_wave_r(const double* __restrict__ src, double* __restrict__ dst, int64_t ld,
+                                                     int nsub, int nt, unsigned* ctr) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = (blockIdx.x * 4 + wave) % nsub;
+  auto pull = [&]() -> unsigned {
+    unsigned t = 0;
+    if (lane == 0) t = atomicAdd(ctr + sub * 32, 1u);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+  };
+  unsigned q0 = pull(), q1 = pull();
+  for (;;) {
+    if (q0 >= (unsigned)nt) break;
+    if (W8 == 1024) {
+      const double* p = src + (int64_t)q0 * R * ld + sub * 128 + 2 * lane;
+      double* o = dst + (int64_t)q0 * R * ld + sub * 128 + 2 * lane;
+      d2 x[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[r] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p + r * ld));
+#pragma unroll
+      for (int r = 0; r < R; ++r) __builtin_nontemporal_store(x[r], reinterpret_cast<d2*>(o + r * ld));
+    } else {
+      const double* p = src + (int64_t)q0 * R * ld + sub * 64 + lane;
+      double* o = dst + (int64_t)q0 * R * ld + sub * 64 + lane;
+      double x[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[r] = __builtin_nontemporal_load(p + r * ld);
+#pragma unroll
+      for (int r = 0; r < R; ++r) __builtin_nontemporal_store(x[r], o + r * ld);
+    }
+    q0 = q1;
+    q1 = pull();
+  }
+}
+
 // the same with look-ahead, as a real kernel needs it: a ticket names a unit of U batches (4 U rows) of the
 // workgroup's strip and is pulled L units before it is used; D batches in flight in registers
 template <int U, int L, int D>
@@ -255,6 +292,17 @@ int main(int argc, char** argv) {
   }
   PW(0, 512) PW(2, 512) PW(3, 512) PW(3, 448) PW(3, 1024)
 #undef PW
+#define PR(R_, W8_, WG_)                                                                                            \
+  {                                                                                                                \
+    char nm[96];                                                                                                   \
+    snprintf(nm, sizeof nm, "independent waves, %2d-row x %4d-byte tiles, %d wgs", R_, W8_, WG_);                   \
+    report(nm, time_ms([&] {                                                                                       \
+      CK(hipMemsetAsync(ctr2, 0, 4 * 32 * 1024, 0));                                                               \
+      hipLaunchKernelGGL((k_pull_wave_r<R_, W8_>), dim3(WG_), dim3(256), 0, 0, src, dst, ld,                       \
+                         (int)(ld * 8 / W8_), m / R_, ctr2); }, reps));                                            \
+  }
+  PR(2, 1024, 512) PR(4, 1024, 512) PR(8, 1024, 512) PR(16, 1024, 512) PR(4, 512, 512) PR(16, 512, 512) PR(16, 512, 384) PR(4, 1024, 384) PR(16, 1024, 384)
+#undef PR
   for (int W : {512}) {
     const int G = W / nstrips;
     char name[96];
