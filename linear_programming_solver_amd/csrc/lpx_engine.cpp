@@ -74,7 +74,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_U", 1, 1, 4},                     // LPX_OPT_UPDATE_U
     {"LPX_ROWS_PER_TILE", 2, 2, 256},       // LPX_OPT_UPDATE_ROWS
     {"LPX_A2_OFFSET", 512, 0, 1 << 20},     // LPX_OPT_A2_OFFSET
-    {"LPX_SWEEP_FORM", 0, 0, 5},            // LPX_OPT_SWEEP_FORM
+    {"LPX_SWEEP_FORM", 0, 0, 4},            // LPX_OPT_SWEEP_FORM
     {"LPX_MULTI_ONEHOP", 0, 0, 1},          // LPX_OPT_MULTI_ONEHOP
     {"LPX_SWEEP_CUS", 0, 0, 256},           // LPX_OPT_SWEEP_CUS
     {"LPX_CHAIN_CUS", 0, 0, 16},            // LPX_OPT_CHAIN_CUS

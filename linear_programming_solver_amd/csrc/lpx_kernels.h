@@ -105,7 +105,7 @@ struct MgPeers {
   unsigned spin_max;                       // bound of the waits between devices in polls (0: the default, 2^22 = seconds)
 };
 // which kernel swept the bulk of the tableau (lpx_state_info.sweep_kernel)
-enum SweepKernel { kSweepNone = 0, kSweepTiles = 1, kSweepMulti = 2, kSweepSteady = 3, kSweepPipe64 = 4, kSweepDma = 5, kSweepPull = 6, kSweepPull64 = 7, kSweepOne64 = 8, kSweepMfma64 = 9, kSweepMfma642 = 10, kSweepMfma643 = 11 };
+enum SweepKernel { kSweepNone = 0, kSweepTiles = 1, kSweepMulti = 2, kSweepSteady = 3, kSweepPipe64 = 4, kSweepDma = 5, kSweepPull = 6, kSweepPull64 = 7, kSweepOne64 = 8, kSweepMfma64 = 9, kSweepMfma642 = 10 };
 struct RestoreEntry { int32_t is_basic; int32_t index; double k; };  // index = row r (basic) or post-drop slot
 
 // ---- launch wrappers --------------------------------------------------------------------------------------------

@@ -3700,15 +3700,8 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 #ifndef LPX_MFMA_SHAPE
 #define LPX_MFMA_SHAPE 0   // copy-shape experiments of the diagnostic builds (1: 4 rows x 256 B per instruction, 2: 2 x 512 B, 3: 1 x 512 B)
 #endif
-#ifndef LPX_MFMA_NBUF
-#define LPX_MFMA_NBUF 3      // tile buffers per wave (experiments: 2)
-#endif
-#ifndef LPX_MFMA_THREADS
-#define LPX_MFMA_THREADS 256 // threads per workgroup (experiments: 384 = three waves per SIMD with two workgroups per CU)
-#endif
-constexpr int kMfma2Threads = LPX_MFMA_THREADS;
 template <bool NT, bool OOP>
-__global__ __launch_bounds__(kMfma2Threads, 2) void k_sweep64_mfma2(double* A, const double* Asrc,   // (no __restrict__: see below)
+__global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const double* Asrc,   // (no __restrict__: see below)
                                                           int64_t ld, int m_local,
                                                           const double* __restrict__ prow_ring,
                                                           const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
@@ -3739,7 +3732,7 @@ __global__ __launch_bounds__(kMfma2Threads, 2) void k_sweep64_mfma2(double* A, c
   const uint32_t off_c = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 8u;   // row lane / 16, column lane % 16
   const uint32_t off_a = (uint32_t)lane * 8u;
   // the B operands of the group's two halves into LDS: the four waves share the 128 (half, group, column tile) images
-  for (int q = wave; q < 2 * NG * CT; q += kMfma2Threads / 64) {
+  for (int q = wave; q < 2 * NG * CT; q += 4) {
     const int h = q / (NG * CT), g = (q / CT) % NG, ct = q % CT;
     const int s = 4 * g + (lane >> 4);
     sh_b[q * 64 + lane] = s < np ? prow_ring[(int64_t)s * ld + grp * 128 + h * 64 + ct * 16 + (lane & 15)] : 0.0;
@@ -3879,27 +3872,6 @@ __global__ __launch_bounds__(kMfma2Threads, 2) void k_sweep64_mfma2(double* A, c
   // Straight-line body, ONE exit at the back edge.  (With `break`s between the steps the compiler folds the exits into
   // one latch block, and its vmcnt bookkeeping then sees paths that skip a step: it waited for the loads the previous
   // step had just issued.)  Tickets only grow, t0 < t1 < ...: once t0 is past the end everything later is.
-#if LPX_MFMA_NBUF == 2   // experiment: ONE tile in flight per wave (c2 / a2 unused; tile t1's loads are in flight at entry)
-#pragma unroll 1
-  do {
-    ticket_pull(k0, ctr);
-    const int t2 = take(k2);
-    LPX_MFMA_FENCE;
-    work_tile(t0, c0, a0);
-    LPX_MFMA_FENCE;
-    load_tile(t2, c0, a0);
-    LPX_MFMA_FENCE;
-    ticket_pull(k2, ctr);
-    const int t3 = take(k0);
-    LPX_MFMA_FENCE;
-    work_tile(t1, c1, a1);
-    LPX_MFMA_FENCE;
-    load_tile(t3, c1, a1);
-    LPX_MFMA_FENCE;
-    t0 = t2; t1 = t3;
-  } while (t0 < ntiles);
-  return;
-#endif
 #pragma unroll 1
   do {
     ticket_pull(k0, ctr);
@@ -3924,128 +3896,6 @@ __global__ __launch_bounds__(kMfma2Threads, 2) void k_sweep64_mfma2(double* A, c
   } while (t0 < ntiles);
 }
 
-// Third form: the tile is 16 rows x 128 columns — a row's whole 1 KiB segment of the group by ONE wave at ONE time.
-// (k_sweep64_mfma2's tile is 16 x 64: the two 512-byte halves of a row go to two waves; as plain copies through the same
-// ticket structure, 16-row x 512-byte tiles stream at 4.9-5.2 TB/s, 16-row x 1 KiB tiles at 5.5: scripts/micro/
-// copy_patterns.hip, profiles/r04_copy_patterns_tall_tiles.txt.)  128 MFMAs per tile on ONE set of A operands (half the A
-// traffic per entry), C of a tile in 64 VGPRs, so two tile buffers instead of three: while a tile is worked, the other
-// buffer's loads are in flight.  A step = { pull a ticket; 128 MFMAs; 32 stores; take the ticket; 40 loads }: the ticket
-// has had the arithmetic's 8 192 cycles to return and its wait (vmcnt(32): the stores behind it) covers nothing the next
-// step's MFMAs do not need anyway.  Everything else as k_sweep64_mfma2: B operands of the group in LDS (64 KiB), buffer
-// addressing, tickets past the end re-read the last tile and have their stores dropped, one exit at the back edge.
-template <bool NT, bool OOP>
-__global__ __launch_bounds__(256, 2) void k_sweep64_mfma3(double* A, const double* Asrc,   // (no __restrict__: as k_sweep64_mfma2)
-                                                          int64_t ld, int m_local,
-                                                          const double* __restrict__ prow_ring,
-                                                          const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
-                                                          const double* colM,   // [tile][group pair][lane][2]
-                                                          unsigned* tickets) {
-  constexpr int NG = 16, CT = 8;
-  constexpr int kRsrcWord3 = 0x00020000;           // raw buffer, 32-bit data format (gfx9 family)
-  constexpr int kAuxNt = NT ? 2 : 0;               // cache policy bit 1 = nt
-  __shared__ __attribute__((aligned(16))) double sh_b[NG * CT * 64];
-  __shared__ int sh_np;
-  const int np = ring_count(ring, 64, kmax, &sh_np);
-  if (np <= 32) return;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int ngroups = nstrips_full * 4;            // groups of 128 columns
-  const int grp = (ngroups % 8 == 0)
-                      ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(ngroups / 8)) % (unsigned)ngroups)
-                      : (int)(blockIdx.x % (unsigned)ngroups);
-  const int ntiles = m_local / 16;
-  unsigned* const ctr = tickets + grp * 32;
-  const int64_t row_bytes = ld * 8;
-  char* const dst_base = reinterpret_cast<char*>(A + grp * 128);
-  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + grp * 128) : dst_base;
-  const uint32_t rb32 = (uint32_t)row_bytes;       // 16 rows x ld x 8 < 2^32 (launcher)
-  const uint32_t off_c = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 8u;   // row lane / 16, column lane % 16
-  const uint32_t off_a = (uint32_t)lane * 16u;
-  for (int q = wave; q < NG * CT; q += 4) {        // B operands: pivot 4 g + lane / 16, column 16 ct + lane % 16 of the group
-    const int g = q / CT, ct = q % CT;
-    const int s = 4 * g + (lane >> 4);
-    sh_b[q * 64 + lane] = s < np ? prow_ring[(int64_t)s * ld + grp * 128 + ct * 16 + (lane & 15)] : 0.0;
-  }
-  __syncthreads();
-  const double* const bl = sh_b + lane;
-  auto load_tile = [&](int t, d4v (&c)[CT], double (&a)[NG]) {
-    const int tt = max(0, min(t, ntiles - 1));                          // uniform; past the end: the last tile again
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(src_base) + (int64_t)tt * 16 * row_bytes, 0, -1, kRsrcWord3);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-        c[ct][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, off_c + (uint32_t)ct * 128u,
-                                                                                   (int)((uint32_t)(4 * r) * rb32), kAuxNt));
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double*>(colM) + (int64_t)tt * 1024, 0, -1, kRsrcWord3);
-#pragma unroll
-    for (int p = 0; p < NG / 2; ++p) {   // (k_pack_multipliers_mfma, pairs: the A operands of groups 2 p and 2 p + 1 side by side)
-      const v4u x = __builtin_amdgcn_raw_buffer_load_b128(ra, off_a + (uint32_t)(p & 3) * 1024u, (p >> 2) * 4096, 0);
-      a[2 * p] = __builtin_bit_cast(double, v2u{x[0], x[1]});
-      a[2 * p + 1] = __builtin_bit_cast(double, v2u{x[2], x[3]});
-    }
-  };
-  auto work_tile = [&](int t, d4v (&c)[CT], const double (&a)[NG]) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-        c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bl[(g * CT + ct) * 64], c[ct], 0, 0, 0);
-    // the B operands of group g + 1 (four ds_read2st64_b64) are asked for in front of group g's eight MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-    }
-    const int tt = max(0, min(t, ntiles - 1));
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-        dst_base + (int64_t)tt * 16 * row_bytes, 0, __builtin_amdgcn_readfirstlane((unsigned)t < (unsigned)ntiles ? -1 : 0), kRsrcWord3);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (double)c[ct][r]), rd, off_c + (uint32_t)ct * 128u,
-                                              (int)((uint32_t)(4 * r) * rb32), kAuxNt);
-  };
-  auto take = [&](unsigned& tk) -> int {   // pulled in front of this step's arithmetic; younger: the step's 32 stores
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    return ticket_take(tk);
-  };
-  d4v c0[CT], c1[CT];
-  double a0[NG], a1[NG];
-  int t0, t1;
-  unsigned k0, k1;
-  {
-    ticket_pull(k0, ctr); ticket_pull(k1, ctr);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    t0 = ticket_take(k0); t1 = ticket_take(k1);
-  }
-  if (t0 >= ntiles) return;
-  load_tile(t0, c0, a0);
-  load_tile(t1, c1, a1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the loop head's bookkeeping is the loop-carried state alone (see k_sweep64_mfma2)
-#pragma unroll 1
-  do {
-    ticket_pull(k0, ctr);
-    LPX_MFMA_FENCE;
-    work_tile(t0, c0, a0);
-    LPX_MFMA_FENCE;
-    const int t2 = take(k0);
-    load_tile(t2, c0, a0);
-    LPX_MFMA_FENCE;
-    ticket_pull(k1, ctr);
-    LPX_MFMA_FENCE;
-    work_tile(t1, c1, a1);
-    LPX_MFMA_FENCE;
-    const int t3 = take(k1);
-    load_tile(t3, c1, a1);
-    LPX_MFMA_FENCE;
-    t0 = t2; t1 = t3;
-  } while (t0 < ntiles);
-}
 #undef LPX_MFMA_FENCE
 #endif  // LPX_FUSED
 
@@ -4669,13 +4519,9 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
     LPX_EACH_NT_OOP(LPX_PRE_MFMA64)
 #undef LPX_PRE_MFMA64
 #define LPX_PRE_MFMA642(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(kMfma2Threads), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, -1);
+    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, -1);
     LPX_EACH_NT_OOP(LPX_PRE_MFMA642)
 #undef LPX_PRE_MFMA642
-#define LPX_PRE_MFMA643(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_mfma3<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
-    LPX_EACH_NT_OOP(LPX_PRE_MFMA643)
-#undef LPX_PRE_MFMA643
 #endif
   }
 #undef LPX_PRE_PULL
@@ -4846,31 +4692,18 @@ static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local
 // blocks of 33..64 on the matrix cores (fused arithmetic only): one wave per SIMD, G workgroups per group of four
 // 64-column sub-strips, 16-row tiles pulled from the sub-strip's ticket counter
 static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                                hipStream_t s, int slots = 256, int variant = 1) {   // 1: k_sweep64_mfma, 2: k_sweep64_mfma2, 3: k_sweep64_mfma3
-  const bool two_waves = variant >= 2;
+                                hipStream_t s, int slots = 256, bool two_waves = false) {
   const int nstrips_full = (int)(B.ld / 512);
   const int ngroups = nstrips_full * 2;
   const int ntiles = m_local / 16;
   const int G = std::max(1, std::min(ntiles, slots / std::max(1, ngroups)));
   hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, s, R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
                      R.tickets, nstrips_full * 8, R.clk, two_waves ? 1 : 0);
-  if (variant == 3) {   // k_sweep64_mfma3: 16-row x 128-column tiles, two workgroups per CU
-    const int ng3 = nstrips_full * 4;
-    const int G3 = std::max(1, std::min(ntiles, 2 * slots / std::max(1, ng3)));
-    const dim3 grid3(ng3 * G3), block3(256);
-#define LPX_LAUNCH_MFMA643(NT_, OOP_)                                                                               \
-    hipLaunchKernelGGL((k_sweep64_mfma3<NT_, OOP_>), grid3, block3, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                       nstrips_full, R.col_packed, R.tickets)
-    if (A_src) { if (nt) LPX_LAUNCH_MFMA643(true, true); else LPX_LAUNCH_MFMA643(false, true); }
-    else { if (nt) LPX_LAUNCH_MFMA643(true, false); else LPX_LAUNCH_MFMA643(false, false); }
-#undef LPX_LAUNCH_MFMA643
-    return;
-  }
   if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
     static const int a_mask = getenv("LPX_SWEEP_DIAG") && atoi(getenv("LPX_SWEEP_DIAG")) == 1 ? 0 : -1;   // timing experiments only
     const int ng2 = nstrips_full * 4;
     const int G2 = std::max(1, std::min(ntiles, 2 * slots / std::max(1, ng2)));
-    const dim3 grid2(ng2 * G2), block2(kMfma2Threads);
+    const dim3 grid2(ng2 * G2), block2(256);
 #define LPX_LAUNCH_MFMA642(NT_, OOP_)                                                                               \
     hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), grid2, block2, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
                        nstrips_full, R.col_packed, R.tickets, a_mask)
@@ -4961,7 +4794,6 @@ const char* sweep_kernel_name(int code) {
     case kSweepOne64: return "k_sweep64_one";
     case kSweepMfma64: return "k_sweep64_mfma";
     case kSweepMfma642: return "k_sweep64_mfma2";
-    case kSweepMfma643: return "k_sweep64_mfma3";
     default: return "";
   }
 }
@@ -5005,12 +4837,12 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     // in LDS: 2.12 vs 2.33 ms per 64 pivots at cfg4), form 4 = k_sweep64_mfma (one wave per SIMD); form 3 = k_sweep64_one there
     bool mfma = false;
 #if LPX_FUSED
-    mfma = one && (form == 0 || form == 4 || form == 5) && m_local % 16 == 0 && 16 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
+    mfma = one && (form == 0 || form == 4) && m_local % 16 == 0 && 16 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
 #endif
     int rows64 = 0;
     if (mfma) {
 #if LPX_FUSED
-      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, form == 0 ? 2 : form == 5 ? 3 : 1);   // form 4: one wave per SIMD (k_sweep64_mfma); 5: k_sweep64_mfma3
+      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, form == 0);   // form 4: one wave per SIMD (k_sweep64_mfma)
 #endif
       rows64 = 16;
     } else if (one) {
@@ -5032,7 +4864,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, complement, 0);
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, complement, 32);
     rows_per_wg = (pull || pipe) ? rows64 : rows;
-    used = mfma ? (form == 0 ? kSweepMfma642 : form == 5 ? kSweepMfma643 : kSweepMfma64) : one ? kSweepOne64 : (pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti));
+    used = mfma ? (form == 0 ? kSweepMfma642 : kSweepMfma64) : one ? kSweepOne64 : (pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti));
 #ifndef LPX_STEADY_PARTIAL
 #define LPX_STEADY_PARTIAL 1
 #endif
