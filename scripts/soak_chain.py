@@ -1,7 +1,9 @@
 """Soak test of the blocked loop's default form (persistent decision kernel beside out-of-place sweeps): many random
 LPs solved to optimality in random budget pieces, every intermediate state compared bit for bit with the fp64
 oracle.  A stale read between workgroups of k_block_chain would show up here as a mismatch.
-    python scripts/soak_chain.py [seconds=120] [MxN,MxN,...] [stop an LP after this many pivots]"""
+    python scripts/soak_chain.py [seconds=120] [MxN,MxN,...] [stop an LP after this many pivots] [fused]
+"fused": handles in the fused-arithmetic mode against the oracle's fused instantiation (heights that are multiples of 16
+send blocks of 33..64 through the matrix cores, k_sweep64_mfma2)."""
 import os
 import sys
 import time
@@ -26,6 +28,10 @@ def main():
     if len(sys.argv) > 2:   # "MxN,MxN,...": e.g. mid-size shapes, where the by-size grids of the decision kernel apply
         shapes = [tuple(int(x) for x in sh.split("x")) for sh in sys.argv[2].split(",")]
     max_lp_pivots = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # stop an LP after about this many pivots (big shapes)
+    fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
+    kind = oracle.FP64_FUSED if fused else oracle.FP64
+    if fused:
+        lps.set_default_arithmetic("fused")
     n_lp = n_cmp = pivots_total = 0
     while time.time() < t_end:
         m, n = shapes[n_lp % len(shapes)]
@@ -38,7 +44,7 @@ def main():
         if n_lp % 4 == 1:
             opts["chain_wgs"] = 33     # the decision kernel at full width also on these small shapes
         st = lps.LPState(A, b, c, block=block, options=opts)
-        ref = oracle.State(A, b, c, kind=oracle.FP64)
+        ref = oracle.State(A, b, c, kind=kind)
         lp_piv = 0
         while True:
             budget = int(rng.choice([-1, 1, block, 3 * block + 1, 257, 1000]))
