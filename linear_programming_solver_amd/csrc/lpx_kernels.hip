@@ -1793,9 +1793,10 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       // the pending pivots in order; their parameters one chunk ahead of the arithmetic, 16-byte LDS reads
       double pe8[2][8];
       int l8[2][8];
+      // (unconditional: a chunk that is not live holds identity values, and reads under a uniform test made the
+      // compiler wait for ALL outstanding LDS reads — the NEXT chunk's included — in front of every chunk's arithmetic)
       auto params = [&](int c) {
-        const int r0 = (c * 8) & (KB - 1);
-        if (c < NC && r0 < last_of(c) && r0 + 8 > first_a(c)) {
+        if (c < NC) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) { pe8[c & 1][q] = sh_pe[c * 8 + q]; l8[c & 1][q] = sh_l[c * 8 + q]; }
         }
@@ -1812,7 +1813,11 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
               const double t_ = submul(a, cv[c * 8 + q], pe8[c & 1][q]);
+#ifdef LPX_CHAIN2_NOSEL   // timing experiment only (wrong in a pending pivot's own row): the chain without its selects
+              a = t_;
+#else
               a = (ig == l8[c & 1][q]) ? pe8[c & 1][q] : t_;
+#endif
             }
           } else {             // (rare) a restart inside this chunk: its steps one by one, the ring value fetched again
             const char* const oc = c < KB / 8 ? oc_o : oc_n;
@@ -1963,9 +1968,8 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       if (j < n) {
         double cs8[2][8], dv8[2][8];
         int e8[2][8];
-        auto params = [&](int c) {
-          const int r0 = (c * 8) & (KB - 1);
-          if (c < NC && r0 < last_of(c) && r0 + 8 > first_b(c)) {
+        auto params = [&](int c) {   // (unconditional, as in phase A)
+          if (c < NC) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
               cs8[c & 1][q] = sh_cs[c * 8 + q]; dv8[c & 1][q] = sh_dv[c * 8 + q]; e8[c & 1][q] = sh_e[c * 8 + q];
@@ -1984,7 +1988,11 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) {
                 const double t_ = submul(x, cs8[c & 1][q], cv[c * 8 + q]);
+#ifdef LPX_CHAIN2_NOSEL
+                x = t_;
+#else
                 x = (j == e8[c & 1][q]) ? dv8[c & 1][q] : t_;
+#endif
               }
             } else {           // (rare) a restart inside this chunk
               const char* const op = c < KB / 8 ? op_o : op_n;
