@@ -1742,6 +1742,21 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     }
     lds_barrier();
     const int ra = chain_restart<KB>(sh_mask);
+    // Which pending pivots have their OWN row among this wave's 64 rows of the first / second pass (bit u = ring slot u;
+    // all lanes are active here, lane u asks for slot u; an empty slot holds -1 and matches nothing).  A step whose bit is
+    // clear needs no "is this the pivot's row" select: the chain is then one multiply-add per step and a scalar bit test,
+    // where the select cost a compare and two v_cndmask on the dependent path of a lone wave (A.chain + B.chain: 1.0 us
+    // of a 15 us decision beside the sweep, profiles/r04_decision_chain_selects.txt).
+    unsigned long long hit_a[2][2 * KB / 64];
+    {
+      const int row_w = (int)(blockIdx.x * NT) + (tid & ~63);
+#pragma unroll
+      for (int h = 0; h < 2 * KB / 64; ++h) {
+        const int lu = sh_l[h * 64 + (tid & 63)];
+        hit_a[0][h] = __ballot((unsigned)(lu - row_w) < 64u);
+        hit_a[1][h] = __ballot((unsigned)(lu - row_w - T) < 64u);
+      }
+    }
     const int fo_a = ra < 0 ? 0 : (ra < KB ? ra + 1 : n_old);
     const int fn_a = ra >= KB ? ra - KB + 1 : 0;
     const bool use_b = P.b_from_tableau && s == 0;
@@ -1784,21 +1799,25 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     if (tid == NT - 1 && !have_rec) { sh_hand[1] = lo32(pc_mine); sh_hand[2] = hi32(pc_mine); }
     lds_barrier();
     LPX_C2_STAMP(8)
+    int pass_a = 0;
     while (i < m) {
       const int ig = i;
+      unsigned long long hm_a[2 * KB / 64];
+#pragma unroll
+      for (int h = 0; h < 2 * KB / 64; ++h) hm_a[h] = pass_a == 0 ? hit_a[0][h] : pass_a == 1 ? hit_a[1][h] : ~0ull;   // (later passes: every step tests)
+      ++pass_a;
       if (ra >= 0) {   // (uniform, rare) the restart value
         const double p_r = sh_p[ra];
         a = (ig == sh_l[ra]) ? __ddiv_rn(1.0, p_r) : -__ddiv_rn(a, p_r);              // :139 / :157
       }
       // the pending pivots in order; their parameters one chunk ahead of the arithmetic, 16-byte LDS reads
       double pe8[2][8];
-      int l8[2][8];
       // (unconditional: a chunk that is not live holds identity values, and reads under a uniform test made the
       // compiler wait for ALL outstanding LDS reads — the NEXT chunk's included — in front of every chunk's arithmetic)
       auto params = [&](int c) {
         if (c < NC) {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) { pe8[c & 1][q] = sh_pe[c * 8 + q]; l8[c & 1][q] = sh_l[c * 8 + q]; }
+          for (int q = 0; q < 8; ++q) pe8[c & 1][q] = sh_pe[c * 8 + q];
         }
       };
       params(0);
@@ -1816,7 +1835,11 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
 #ifdef LPX_CHAIN2_NOSEL   // timing experiment only (wrong in a pending pivot's own row): the chain without its selects
               a = t_;
 #else
-              a = (ig == l8[c & 1][q]) ? pe8[c & 1][q] : t_;
+              a = t_;
+              if ((hm_a[(c * 8 + q) / 64] >> ((c * 8 + q) & 63)) & 1) {   // (uniform, rare) the pivot's own row is in this wave
+                asm volatile("" ::: "memory");   // (keeps the test a scalar branch: if-converted it is the select again)
+                if (ig == sh_l[c * 8 + q]) a = pe8[c & 1][q];
+              }
 #endif
             }
           } else {             // (rare) a restart inside this chunk: its steps one by one, the ring value fetched again
@@ -1924,6 +1947,17 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     }
     lds_barrier();
     const int rb = chain_restart<KB>(sh_mask);
+    // the same for the columns: which pending pivots ENTERED at one of this wave's 64 slots of the first / second pass
+    unsigned long long hit_b[2][2 * KB / 64];
+    {
+      const int col_w = __builtin_amdgcn_readfirstlane(jfirst);   // (a wave's lanes own consecutive slots)
+#pragma unroll
+      for (int h = 0; h < 2 * KB / 64; ++h) {
+        const int eu = sh_e[h * 64 + (tid & 63)];
+        hit_b[0][h] = __ballot((unsigned)(eu - col_w) < 64u);
+        hit_b[1][h] = __ballot((unsigned)(eu - col_w - jstep) < 64u);
+      }
+    }
     const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
     const int fn_b = rb >= KB ? rb - KB + 1 : 0;
     auto first_b = [&](int c) { return c < KB / 8 ? fo_b : fn_b; };
@@ -1964,16 +1998,18 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     }
     lds_barrier();
     LPX_C2_STAMP(13)
+    int pass_b = 0;
     while (j < (int)ld) {
+      unsigned long long hm_b[2 * KB / 64];
+#pragma unroll
+      for (int h = 0; h < 2 * KB / 64; ++h) hm_b[h] = pass_b == 0 ? hit_b[0][h] : pass_b == 1 ? hit_b[1][h] : ~0ull;
+      ++pass_b;
       if (j < n) {
-        double cs8[2][8], dv8[2][8];
-        int e8[2][8];
+        double cs8[2][8];
         auto params = [&](int c) {   // (unconditional, as in phase A)
           if (c < NC) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              cs8[c & 1][q] = sh_cs[c * 8 + q]; dv8[c & 1][q] = sh_dv[c * 8 + q]; e8[c & 1][q] = sh_e[c * 8 + q];
-            }
+            for (int q = 0; q < 8; ++q) cs8[c & 1][q] = sh_cs[c * 8 + q];
           }
         };
         params(0);
@@ -1991,7 +2027,11 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
 #ifdef LPX_CHAIN2_NOSEL
                 x = t_;
 #else
-                x = (j == e8[c & 1][q]) ? dv8[c & 1][q] : t_;
+                x = t_;
+                if ((hm_b[(c * 8 + q) / 64] >> ((c * 8 + q) & 63)) & 1) {   // (uniform, rare) the pivot entered at a slot of this wave
+                  asm volatile("" ::: "memory");
+                  if (j == sh_e[c * 8 + q]) x = sh_dv[c * 8 + q];
+                }
 #endif
               }
             } else {           // (rare) a restart inside this chunk

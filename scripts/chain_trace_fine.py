@@ -26,9 +26,10 @@ st.simplex_loop(max_pivots=pivots - 1)
 tr = st.chain_trace_fine()
 info = st.info()
 names = ["A.loads", "A.chain", "X", "B.loads", "B.chain", "B.rest", "H"]
-live = tr[(tr[:, 0] != 0) & (tr[:, -1] >= tr[:, -2])]
+last = 7 if tr.shape[1] == 16 else tr.shape[1] - 1     # (16 stamps: slots 0..7 are the coarse ones, 7 the decision's last)
+live = tr[(tr[:, 0] != 0) & (tr[:, last] >= tr[:, last - 1])]
 seg = np.diff(live, axis=1) / 100.0
-tot = (live[:, -1] - live[:, 0]) / 100.0
+tot = (live[:, last] - live[:, 0]) / 100.0
 print("%s %dx%d %s: grid %d, %d decisions, per decision mean %.2f median %.2f us" % (
     wl, m, n, {k: v for k, v in opts.items() if k != "chain_trace"}, info["chain_wgs"], len(live), tot.mean(), np.median(tot)))
 if tr.shape[1] == 16:   # diagnostic build (-DLPX_CHAIN2_FINE): stamps in time order
