@@ -103,32 +103,40 @@ def loop_bound(ms_per_step, pivots_per_launch, avg_kernel_ms, info=None):
     """Which of the two concurrent halves of the blocked loop sets the pace: one sweep launch applies
     `pivots_per_launch` pivots while the decisions of the next block are taken beside it, so a block costs
     max(decisions, sweep).  "decisions" when the block takes 10 % longer than its sweep (the sweep kernel then idles
-    part of the time and its roofline fraction says nothing about the loop), else "sweep"."""
+    part of the time and its roofline fraction says nothing about the loop), else "sweep".  Between the two, a block up to
+    25 % longer than its sweep is what the sweep's own stream adds behind it — the fix-up of the block's rows and columns
+    (0.2 ms for a block of 64 at cfg4), the multiplier pack, launch gaps — and the first block's decisions, which nothing
+    hides, spread over the call: "sweep + fix-up".  `other_ms` = block - sweep."""
     try:
         if not (avg_kernel_ms > 0) or not (pivots_per_launch >= 2):
             return None
         block_ms = ms_per_step * pivots_per_launch
         if info is not None and not info.get("overlapped", 1):   # a budget of one block: nothing runs side by side
             return {"block_ms": block_ms, "sweep_ms": avg_kernel_ms, "bound": "serial: the decisions, then one sweep"}
-        return {"block_ms": block_ms, "sweep_ms": avg_kernel_ms,
-                "bound": "decisions" if block_ms > 1.1 * avg_kernel_ms else "sweep"}
+        ratio = block_ms / avg_kernel_ms
+        return {"block_ms": block_ms, "sweep_ms": avg_kernel_ms, "other_ms": block_ms - avg_kernel_ms,
+                "bound": "sweep" if ratio <= 1.1 else ("sweep + fix-up" if ratio <= 1.25 else "decisions")}
     except Exception:
         return None
 
 
-def load_traffic(workload, world, block, kernel):
-    """PMC-measured HBM bytes per launch (profiles/traffic_*.json, scripts/pmc_traffic.py) and where the figure comes
-    from — only when that file was measured for this workload, GPU count, pivots per sweep AND kernel; otherwise
-    (None, None): the number is a property of another run (TCC counters cannot be read from inside bench.py)."""
-    name = "traffic_%s_n%d.json" % (workload, world)
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", name)))
-        if int(t.get("pivots_per_sweep", -1)) == int(block) and t.get("kernel") == kernel:
-            return t.get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "kernel": t.get("kernel"),
-                                                   "steps": t.get("steps"), "date": t.get("date"),
-                                                   "note": "rocprofv3 --pmc passes of this command on another box"}
-    except Exception:
-        pass
+def load_traffic(workload, world, block, kernel, fused=False):
+    """PMC-measured HBM bytes per launch (profiles/*traffic_*.json, scripts/pmc_traffic.py) and where the figure comes
+    from — only when a file was measured for this workload, GPU count, pivots per sweep AND kernel (the fused-arithmetic
+    legs have files of their own, measured in that mode); otherwise (None, None): the number is a property of another run
+    (TCC counters cannot be read from inside bench.py)."""
+    names = ["traffic_%s_n%d.json" % (workload, world)]
+    if fused and world == 1:
+        names.insert(0, "r04_traffic_%s_fused_block%d.json" % (workload, int(block)))
+    for name in names:
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if int(t.get("pivots_per_sweep", -1)) == int(block) and t.get("kernel") == kernel:
+                return t.get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "kernel": t.get("kernel"),
+                                                       "steps": t.get("steps"), "date": t.get("date"),
+                                                       "note": "rocprofv3 --pmc passes of this command on another box"}
+        except Exception:
+            pass
     return None, None
 
 
@@ -434,7 +442,7 @@ def main():
     def measured(r, mw, nw, name, Aw, bw, cw, with_parity):
         """one measurement as an object of the JSON line: value, roofline of its sweep / row-update launch, oracle replay"""
         kern = kernel_label(r["block"], r["info"])
-        traffic, tsrc = load_traffic(name, 1, r["block"], kern)
+        traffic, tsrc = load_traffic(name, 1, r["block"], kern, fused=r.get("fused", False))
         o = {"workload": "%s: m=%d n=%d, %d pivots after %d warm-up" % (name, mw, nw, r["steps"], r["warmup"]),
              "value": r["steps"] / r["elapsed"], "unit": "pivots/s", "ms_per_step": 1e3 * r["elapsed"] / r["steps"],
              "steps": r["steps"], "warmup": r["warmup"], "pivots_per_sweep": r["block"],

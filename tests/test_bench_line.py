@@ -27,11 +27,25 @@ def test_roofline_block_is_bounded_and_names_the_binding_term():
     assert bench.roofline_block(8192, 16384, 32, float("nan"), "k", 0)["frac"] is None
 
 
+def test_traffic_files_match_their_kernel_and_mode():
+    """roofline.traffic is quoted only from a counter file of the same workload, block size, kernel — and, for the
+    fused legs, the file measured in that mode."""
+    t, src = bench.load_traffic("cfg4", 1, 64, "k_sweep64_mfma2", fused=True)
+    assert t and src["file"].endswith("r04_traffic_cfg4_fused_block64.json") and 1.0 < t / (16.0 * 32768 * 16384) < 1.06
+    assert bench.load_traffic("cfg4", 1, 64, "k_sweep64_mfma2", fused=False) == (None, None)
+    assert bench.load_traffic("cfg4", 1, 32, "k_sweep64_mfma2", fused=True) == (None, None)
+    t32, src32 = bench.load_traffic("cfg4", 1, 32, "k_sweep32_pull", fused=True)
+    assert t32 and src32["file"].endswith("fused_block32.json")
+
+
 def test_loop_bound_names_the_slower_half():
     # cfg4 steady: a block of 32 pivots every 1.945 ms, its sweep 1.786 ms -> the sweep sets the pace
     assert bench.loop_bound(1.945 / 32, 32, 1.786, {"overlapped": 1})["bound"] == "sweep"
     # cfg3 steady: 0.665 ms per block, sweep 0.484 ms -> the decisions do
     assert bench.loop_bound(0.665 / 32, 32, 0.484, {"overlapped": 1})["bound"] == "decisions"
+    # cfg4, fused mode, blocks of 64: the sweep 1.895 ms, the block 2.32 ms: the fix-up and the pack behind the sweep
+    lb = bench.loop_bound(2.32 / 64, 64, 1.895, {"overlapped": 1})
+    assert lb["bound"] == "sweep + fix-up" and abs(lb["other_ms"] - 0.425) < 1e-9
     # a budget of one block (the driver's 20 pivots): nothing runs side by side
     assert bench.loop_bound(1.87 / 20, 20, 1.40, {"overlapped": 0})["bound"].startswith("serial")
     # one pass per pivot has no second half
