@@ -608,9 +608,11 @@ int choose_block(const lpx_state* s) {
     // beside them: +3..5 % over 32 from 4 GiB to 12 GiB tableaux (profiles/r02_block64_policy.txt), -22 % at 2 GiB.
     // By size only from ~7 GiB up (8 GiB +4.3 %, 12 GiB +5.4 %), where the kernel applies; opt-in below.
     if (sweep_us >= 2500.0 && s->m % 4 == 0 && s->B.ld >= 512) K = 64;
-    // fused arithmetic: blocks of 33..64 run on the matrix cores (k_sweep64_mfma, 16-row tiles) and pay from ~2.5 GiB
-    // (profiles/r04_arith_grid_*: cfg4 24.2k vs 19.1k pivots/s with blocks of 32; cfg3, 1 GiB: 55.0k vs 54.8k, a tie)
-    if (s->B.fused && sweep_us >= 700.0 && s->m % 16 == 0 && s->B.ld >= 512 && s->m_global == s->m) K = 64;
+    // fused arithmetic: blocks of 33..64 run on the matrix cores (k_sweep64_mfma2, 16-row tiles) and pay from ~1.1 GiB
+    // (profiles/r04_block_by_size_fused.txt, same box, pivots/s with blocks of 64 / 32: 1.125 GiB 54.3k / 52.5k, 1.25 GiB
+    // 53.0k / 48.0k, 1.5 GiB 50.3-52.4k / 38.1-42.7k, cfg4 27.5k / 18.2k; 1 GiB — cfg3 — 54.0-55.0k / 54.9-55.3k: a tie,
+    // blocks of 32 there; 0.5 GiB 57-60k / 67-70k)
+    if (s->B.fused && sweep_us >= 380.0 && s->m % 16 == 0 && s->B.ld >= 512 && s->m_global == s->m) K = 64;
   }
   // three launches per decision (option chain = 0, the form the shards use): its kernels hold at most 32 pending pivots
   if (!s->opt[LPX_OPT_CHAIN] || s->m_global != s->m) K = std::min(K, (int)lpxk::kShardBlockMax);
