@@ -601,7 +601,8 @@ int choose_block(const lpx_state* s) {
     // 16 MiB two-launch 71.1k vs K = 16 69.7k; 20 MiB 66.2k vs 69.2k; 32 MiB 56.7k vs 70.0k;
     // 256 MiB K = 16 67.2k vs K = 32 65.8k; 384-448 MiB equal; 512 MiB 59.6k vs 63.2k; 1 GiB K = 32 50.6k vs 32.8k
     if (sweep_us < 6.3) K = 1;         // up to ~18 MiB: the two-launch loop wins
-    else if (sweep_us < 150.0) K = 16; // up to ~430 MiB
+    else if (sweep_us < 115.0) K = 16; // up to ~330 MiB (round 4, with k_block_chain2: 384 MiB 70.4k pivots/s with 32 against
+                                        // 67.1-68.1k with 16, 256 MiB a tie; profiles/r04_block_by_size_small.txt)
     else K = 32;
     // 64: the two-stage sweep moves half the bytes per pivot and takes 0.74x the time per pivot alone on the chip, but
     // 64-slot decisions cost twice as much each (their ring reads grow with K^2) and take bandwidth from the sweep
