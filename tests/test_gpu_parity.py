@@ -981,10 +981,10 @@ def test_wide_decision_kernel_vs_oracle(lps, oracle, shape, fences, block):
 
 
 @pytest.mark.parametrize("shape,block,wgs", [((1024, 2048), 1, None), ((1280, 2048), 16, 9), ((2048, 4096), 16, 17),
-                                             ((4096, 8192), 16, 32), ((8192, 8192), 32, 32)])
+                                             ((4096, 8192), 16, 32), ((6144, 8192), 32, 32), ((8192, 8192), 32, 32)])
 def test_block_and_decision_grid_by_size(lps, oracle, shape, block, wgs):
     """The by-size choices of the default loop (profiles/r03_block_policy.txt, r03_decision_grid.txt): one pass per pivot
-    up to ~18 MiB, blocks of 16 up to ~430 MiB, 32 above; the decision kernel with one row / column per thread (+ the
+    up to ~18 MiB, blocks of 16 up to ~330 MiB (round 4: profiles/r04_block_by_size_small.txt), 32 above; the decision kernel with one row / column per thread (+ the
     workgroup of the hand-off window), within the 32 CUs of its masked stream.  150 pivots against the fp64 oracle."""
     m, n = shape
     A, b, c = dense_lp(m, n, seed=m + 7 * n)
