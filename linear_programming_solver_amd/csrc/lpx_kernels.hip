@@ -4099,6 +4099,14 @@ __device__ __forceinline__ double apply_pivot(double v, int i, int j, int l_r, i
 // pending pivots from the saved stale values.  grid = (ceil(max(m, ld)/256), ceil(K / 8), 3): a thread takes EIGHT
 // pending pivots' columns (rows) of its row (column) at once, so that a ring value it loads serves eight chains (one
 // pivot per thread re-read the K x m / K x ld ring values K times over: 1.6 GB of L2 traffic per block of 64 at cfg4).
+// The case analysis of apply_pivot per (pending pivot r, chain q) made the kernel instruction-bound (~7 700 instructions
+// per thread for 512 multiply-adds: 215 us per block of 64 at cfg4, and NOT its scattered 8-byte column writes — written to
+// a compact image instead it took 195, EXPERIMENTS.md).  None of its tests depends on the thread:
+//   * "chain q's pivot entered at (left through) the same slot (row) as pivot r" is a property of the block: one 8-bit
+//     mask per r, computed once per workgroup (sh_eq);
+//   * "this thread's row (column) is pivot r's own" can only hold in the one wave whose 64 rows (columns) contain it: one
+//     __ballot per wave (lane r asks for pivot r), then a scalar bit test per r.
+// A step without either is eight multiply-adds on eight LDS values; with one, the old selects behind a uniform branch.
 constexpr int kFixChunk = 8;
 __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int64_t ld, int n, int m_local, int row0,
                                                      double* b, const double* __restrict__ prow_ring,
@@ -4107,58 +4115,82 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
                                                      const double* __restrict__ row0_ring, int64_t mp,
                                                      const LpxCtl* __restrict__ ring, int kmax,
                                                      const double* b_src, long long* __restrict__ clk) {
+  static_assert(kBlockMax <= 64, "one lane per pending pivot in the hit ballots");
   if (clk && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     const unsigned x = xcc_id() & 7u;
     clk[x * 4 + 2] = __builtin_amdgcn_s_memtime(); clk[x * 4 + 3] = wall_clock64();
   }
   __shared__ double sh_p[kBlockMax], sh_bl[kBlockMax];
-  __shared__ double sh_x[kBlockMax][kFixChunk];   // job 0: prow_r[e_s]; job 1: col_r[l_s]   (r: all pivots, s: this chunk's)
-  __shared__ int sh_e[kBlockMax], sh_l[kBlockMax];
+  __shared__ __attribute__((aligned(16))) double sh_x[kBlockMax][kFixChunk];   // job 0: prow_r[e_s]; job 1: col_r[l_s]   (r: all pivots, s: this chunk's)
+  __shared__ int sh_e[kBlockMax], sh_l[kBlockMax], sh_eq[kBlockMax];
   __shared__ int sh_np;
   const int s0 = blockIdx.y * kFixChunk, job = blockIdx.z;
   const int np = ring_count(ring, kBlockMax, kmax, &sh_np);
   if (job == 2 ? s0 != 0 : s0 >= np) return;  // the b job also runs for an empty block (out of place: it copies b)
-  if ((int)threadIdx.x < np) {
-    const LpxCtl& q = ring[threadIdx.x];
-    sh_e[threadIdx.x] = q.e_cur;
-    sh_l[threadIdx.x] = q.l - row0;
-    sh_p[threadIdx.x] = q.p;
-    sh_bl[threadIdx.x] = q.bl;
+  if ((int)threadIdx.x < kBlockMax) {   // (slots behind the last pivot: -1, matches nothing)
+    const bool live = (int)threadIdx.x < np;
+    const LpxCtl& q = ring[live ? threadIdx.x : 0];
+    sh_e[threadIdx.x] = live ? q.e_cur : -1;
+    sh_l[threadIdx.x] = live ? q.l - row0 : -1;
+    sh_p[threadIdx.x] = live ? q.p : 1.0;
+    sh_bl[threadIdx.x] = live ? q.bl : 0.0;
   }
   __syncthreads();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int ns = min(kFixChunk, np - s0);   // pivots of this chunk (job 0 / 1)
+  const int lane = threadIdx.x & 63;
+  const int t_wave = t - lane;              // the wave's first row (job 0, 2) / column (job 1)
   if (job == 0) {  // entering columns of pending pivots s0 .. s0 + ns - 1, all local rows
     for (int idx = threadIdx.x; idx < np * kFixChunk; idx += blockDim.x) {
       const int r = idx / kFixChunk, q = idx % kFixChunk;
       sh_x[r][q] = q < ns ? prow_ring[(int64_t)r * ld + sh_e[s0 + q]] : 0.0;
     }
+    if ((int)threadIdx.x < np) {   // which chains of the chunk entered at pivot r's slot (the division of :157)
+      int mask = 0;
+      for (int q = 0; q < ns; ++q) mask |= (sh_e[s0 + q] == sh_e[threadIdx.x]) << q;
+      sh_eq[threadIdx.x] = mask;
+    }
     __syncthreads();
+    // pivots whose own row is one of this wave's 64 rows (all lanes active here: lane r asks for pivot r)
+    const unsigned long long hit = __ballot((unsigned)(sh_l[lane] - t_wave) < 64u);
     if (t < m_local) {
       double v[kFixChunk];
 #pragma unroll
       for (int q = 0; q < kFixChunk; ++q) v[q] = q < ns ? col0_ring[(int64_t)(s0 + q) * mp + t] : 0.0;
-      // the ring values of eight steps are requested together (they do not depend on the running values)
-      for (int r0 = 0; r0 < np; r0 += 8) {
-        double cv[8];
+      // the ring values of eight steps are requested together (they do not depend on the running values), one batch
+      // ahead of the arithmetic that uses them
+      double cv[8], cvn[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cv[u] = (r0 + u < np) ? col_ring[(int64_t)(r0 + u) * mp + t] : 0.0;
+      for (int u = 0; u < 8; ++u) cv[u] = (u < np) ? col_ring[(int64_t)u * mp + t] : 0.0;
+      for (int r0 = 0; r0 < np; r0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cvn[u] = (r0 + 8 + u < np) ? col_ring[(int64_t)(r0 + 8 + u) * mp + t] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int r = r0 + u;
-          if (r < np) {
+          if (r < np) {   // (uniform)
+            double x[kFixChunk];
 #pragma unroll
-            for (int q = 0; q < kFixChunk; ++q)
-              if (q < ns) {
-                // (the full case analysis of apply_pivot; the division only where a chain really takes it — same
-                // entering slot as pivot r: decided per (r, q), the same in every lane)
+            for (int q = 0; q < kFixChunk; ++q) x[q] = sh_x[r][q];
+            const int eq = __builtin_amdgcn_readfirstlane(sh_eq[r]);
+            if (eq == 0 && !((hit >> r) & 1)) {   // (uniform, the common case) eight plain steps
+#pragma unroll
+              for (int q = 0; q < kFixChunk; ++q) v[q] = submul(v[q], cv[u], x[q]);                    // :162
+            } else {
+              const double pr = sh_p[r];
+              const bool own = t == sh_l[r];
+#pragma unroll
+              for (int q = 0; q < kFixChunk; ++q) {
                 double nv;
-                if (sh_e[s0 + q] == sh_e[r]) nv = -__ddiv_rn(cv[u], sh_p[r]);                 // :157
-                else nv = submul(v[q], cv[u], sh_x[r][q]);                                    // :162
-                v[q] = (t == sh_l[r]) ? sh_x[r][q] : nv;   // pivot row := normalised row
+                if ((eq >> q) & 1) nv = -__ddiv_rn(cv[u], pr);                                          // :157
+                else nv = submul(v[q], cv[u], x[q]);                                                   // :162
+                v[q] = own ? x[q] : nv;   // pivot row := normalised row
               }
+            }
           }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cv[u] = cvn[u];
       }
 #pragma unroll
       for (int q = 0; q < kFixChunk; ++q)
@@ -4170,29 +4202,50 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
       const int i = q < ns ? sh_l[s0 + q] : -1;
       sh_x[r][q] = (i >= 0 && i < m_local) ? col_ring[(int64_t)r * mp + i] : 0.0;
     }
+    if ((int)threadIdx.x < np) {   // which chains of the chunk left through pivot r's row (row := normalised row)
+      int mask = 0;
+      for (int q = 0; q < ns; ++q) mask |= (sh_l[s0 + q] == sh_l[threadIdx.x]) << q;
+      sh_eq[threadIdx.x] = mask;
+    }
     __syncthreads();
+    // pivots that entered at one of this wave's 64 slots (the division of :157 sits in THAT column)
+    const unsigned long long hit = __ballot((unsigned)(sh_e[lane] - t_wave) < 64u);
     if (t < (int)ld) {
       double v[kFixChunk];
 #pragma unroll
       for (int q = 0; q < kFixChunk; ++q) v[q] = (q < ns && t < n) ? row0_ring[(int64_t)(s0 + q) * ld + t] : 0.0;
-      for (int r0 = 0; r0 < np; r0 += 8) {
-        double pv[8];
+      double pv[8], pvn[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pv[u] = (r0 + u < np) ? prow_ring[(int64_t)(r0 + u) * ld + t] : 0.0;
+      for (int u = 0; u < 8; ++u) pv[u] = (u < np) ? prow_ring[(int64_t)u * ld + t] : 0.0;
+      for (int r0 = 0; r0 < np; r0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pvn[u] = (r0 + 8 + u < np) ? prow_ring[(int64_t)(r0 + 8 + u) * ld + t] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int r = r0 + u;
-          if (r < np) {
+          if (r < np) {   // (uniform)
+            double x[kFixChunk];
 #pragma unroll
-            for (int q = 0; q < kFixChunk; ++q)
-              if (q < ns) {
+            for (int q = 0; q < kFixChunk; ++q) x[q] = sh_x[r][q];
+            const int eq = __builtin_amdgcn_readfirstlane(sh_eq[r]);
+            if (eq == 0 && !((hit >> r) & 1)) {
+#pragma unroll
+              for (int q = 0; q < kFixChunk; ++q) v[q] = submul(v[q], x[q], pv[u]);
+            } else {
+              const double pr = sh_p[r];
+              const bool own = t == sh_e[r];   // (one thread of the grid per pivot r)
+#pragma unroll
+              for (int q = 0; q < kFixChunk; ++q) {
                 double nv;
-                if (t == sh_e[r]) nv = -__ddiv_rn(sh_x[r][q], sh_p[r]);   // (one thread of the grid per pivot r)
-                else nv = submul(v[q], sh_x[r][q], pv[u]);
-                v[q] = (sh_l[s0 + q] == sh_l[r]) ? pv[u] : nv;
+                if (own) nv = -__ddiv_rn(x[q], pr);
+                else nv = submul(v[q], x[q], pv[u]);
+                v[q] = ((eq >> q) & 1) ? pv[u] : nv;
               }
+            }
           }
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = pvn[u];
       }
 #pragma unroll
       for (int q = 0; q < kFixChunk; ++q) {
@@ -4201,6 +4254,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
       }
     }
   } else {  // b of every local row (LPState.java:164 / :146)
+    const unsigned long long hit = __ballot((unsigned)(sh_l[lane] - t_wave) < 64u);
     if (t < m_local) {
       double bi = b_src[t];  // == b unless the sweep ran out of place
       for (int r0 = 0; r0 < np; r0 += 8) {
@@ -4210,7 +4264,11 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int r = r0 + q;
-          if (r < np) bi = (t == sh_l[r]) ? sh_bl[r] : submul(bi, cv[q], sh_bl[r]);
+          if (r < np) {
+            const double nb = submul(bi, cv[q], sh_bl[r]);
+            bi = nb;
+            if ((hit >> r) & 1) { if (t == sh_l[r]) bi = sh_bl[r]; }
+          }
         }
       }
       b[t] = bi;
