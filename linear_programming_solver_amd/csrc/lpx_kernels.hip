@@ -4159,13 +4159,12 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
       for (int q = 0; q < kFixChunk; ++q) v[q] = q < ns ? col0_ring[(int64_t)(s0 + q) * mp + t] : 0.0;
       // the ring values of eight steps are requested together (they do not depend on the running values), one batch
       // ahead of the arithmetic that uses them
-      // (a slot behind the last pivot is clamped to the last one: a load without a branch, its value unused)
       double cv[8], cvn[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) cv[u] = col_ring[(int64_t)min(u, np - 1) * mp + t];
+      for (int u = 0; u < 8; ++u) cv[u] = (u < np) ? col_ring[(int64_t)u * mp + t] : 0.0;
       for (int r0 = 0; r0 < np; r0 += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cvn[u] = col_ring[(int64_t)min(r0 + 8 + u, np - 1) * mp + t];
+        for (int u = 0; u < 8; ++u) cvn[u] = (r0 + 8 + u < np) ? col_ring[(int64_t)(r0 + 8 + u) * mp + t] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int r = r0 + u;
@@ -4177,12 +4176,14 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
             if (eq == 0 && !((hit >> r) & 1)) {   // (uniform, the common case) eight plain steps
 #pragma unroll
               for (int q = 0; q < kFixChunk; ++q) v[q] = submul(v[q], cv[u], x[q]);                    // :162
-            } else {   // (rare; one division for the chunk, not one per chain: the instruction cache holds the loop)
-              const double dv = -__ddiv_rn(cv[u], sh_p[r]);                                            // :157
+            } else {
+              const double pr = sh_p[r];
               const bool own = t == sh_l[r];
 #pragma unroll
               for (int q = 0; q < kFixChunk; ++q) {
-                const double nv = ((eq >> q) & 1) ? dv : submul(v[q], cv[u], x[q]);                    // :162
+                double nv;
+                if ((eq >> q) & 1) nv = -__ddiv_rn(cv[u], pr);                                          // :157
+                else nv = submul(v[q], cv[u], x[q]);                                                   // :162
                 v[q] = own ? x[q] : nv;   // pivot row := normalised row
               }
             }
@@ -4215,10 +4216,10 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
       for (int q = 0; q < kFixChunk; ++q) v[q] = (q < ns && t < n) ? row0_ring[(int64_t)(s0 + q) * ld + t] : 0.0;
       double pv[8], pvn[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) pv[u] = prow_ring[(int64_t)min(u, np - 1) * ld + t];
+      for (int u = 0; u < 8; ++u) pv[u] = (u < np) ? prow_ring[(int64_t)u * ld + t] : 0.0;
       for (int r0 = 0; r0 < np; r0 += 8) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pvn[u] = prow_ring[(int64_t)min(r0 + 8 + u, np - 1) * ld + t];
+        for (int u = 0; u < 8; ++u) pvn[u] = (r0 + 8 + u < np) ? prow_ring[(int64_t)(r0 + 8 + u) * ld + t] : 0.0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int r = r0 + u;
@@ -4230,14 +4231,14 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
             if (eq == 0 && !((hit >> r) & 1)) {
 #pragma unroll
               for (int q = 0; q < kFixChunk; ++q) v[q] = submul(v[q], x[q], pv[u]);
-            } else {   // (rare)
+            } else {
               const double pr = sh_p[r];
               const bool own = t == sh_e[r];   // (one thread of the grid per pivot r)
-#pragma unroll 1
+#pragma unroll
               for (int q = 0; q < kFixChunk; ++q) {
-                const double xq = sh_x[r][q];
-                double nv = submul(v[q], xq, pv[u]);
-                if (own) nv = -__ddiv_rn(xq, pr);
+                double nv;
+                if (own) nv = -__ddiv_rn(x[q], pr);
+                else nv = submul(v[q], x[q], pv[u]);
                 v[q] = ((eq >> q) & 1) ? pv[u] : nv;
               }
             }
@@ -4259,7 +4260,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
       for (int r0 = 0; r0 < np; r0 += 8) {
         double cv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) cv[q] = col_ring[(int64_t)min(r0 + q, np - 1) * mp + t];
+        for (int q = 0; q < 8; ++q) cv[q] = (r0 + q < np) ? col_ring[(int64_t)(r0 + q) * mp + t] : 0.0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int r = r0 + q;
