@@ -4125,6 +4125,8 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
   __shared__ int sh_e[kBlockMax], sh_l[kBlockMax], sh_eq[kBlockMax];
   __shared__ int sh_np;
   const int s0 = blockIdx.y * kFixChunk, job = blockIdx.z;
+  // (the grid is max(m, ld) wide for all three jobs: a workgroup with nothing to do leaves before the ring is looked at)
+  if ((int64_t)blockIdx.x * blockDim.x >= (job == 1 ? ld : (int64_t)m_local) || (job == 2 && s0 != 0)) return;
   const int np = ring_count(ring, kBlockMax, kmax, &sh_np);
   if (job == 2 ? s0 != 0 : s0 >= np) return;  // the b job also runs for an empty block (out of place: it copies b)
   if ((int)threadIdx.x < kBlockMax) {   // (slots behind the last pivot: -1, matches nothing)
