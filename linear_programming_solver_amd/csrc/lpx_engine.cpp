@@ -164,6 +164,7 @@ static void free_block_ring(lpx_state* s) {
   (void)hipFree(s->R.chain_own_prow);
   (void)hipFree(s->R.chain_own_dvc);
   (void)hipFree(s->R.chain_own_b);
+  (void)hipFree(s->R.chain_own_rs);
   (void)hipFree(s->R.chain_dbg);
   (void)hipFree(s->R.census);
   (void)hipFree(const_cast<double*>(s->R.zeros));
@@ -547,6 +548,8 @@ static int build_block_ring(lpx_state* s) {
   HIP_TRY(hipMalloc((void**)&s->R.chain_own_prow, K * (size_t)s->B.ld * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.chain_own_dvc, K * (size_t)mp * sizeof(double)));
   HIP_TRY(hipMalloc((void**)&s->R.chain_own_b, (size_t)mp * sizeof(double)));
+  HIP_TRY(hipMalloc((void**)&s->R.chain_own_rs, (size_t)(mp + s->B.ld) * sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(s->R.chain_own_rs, 0xff, (size_t)(mp + s->B.ld) * sizeof(int32_t), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.chain_own_col, 0, K * (size_t)mp * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.chain_own_prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.chain_dbg, 16 * lpxk::kBlockMax * sizeof(long long)));   // 5 (k_block_chain_t) or 8 stamps per decision

@@ -78,6 +78,7 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   double* chain_own_prow;  // kBlockMax x ld: likewise for `prow`
   double* chain_own_dvc;   // kBlockMax x mp: column e_s of the tableau just AFTER pivot s (restart point)
   double* chain_own_b;     // mp: b with all pending pivots applied
+  int32_t* chain_own_rs;   // mp + ld: k_block_chain2's start indices per row / per slot (last pending pivot that replaced it)
   long long* chain_dbg;    // diagnostics (LPX_OPT_CHAIN_TRACE): 5 timestamps per decision of the last block
   unsigned* census;        // [w] = XCC id + 1 of chain workgroup w; [kChainMaxWgs] = OR of (1 << XCC id) of sampled sweep workgroups
   double* col_packed;      // k_sweep32_pull: the block's multipliers as [batch of 4 rows][pivot][row]: (mp / 4) x 1 KiB (2 KiB for blocks of 64)

@@ -982,6 +982,7 @@ struct ChainArgs {
   const LpxCtl* up_o;
   int n_old;
   double* own_b;        // b with every decided pivot applied (kept across the launches of one loop)
+  int32_t *own_rs_a, *own_rs_b;   // k_block_chain2: per row / slot, the last pending pivot that replaced it (LDS index, -1: none)
   int b_from_tableau;   // 1: first launch of a loop, own_b is not valid before decision 0
   int nb;
   ChainPart* partA;
@@ -1007,7 +1008,7 @@ struct ChainArgs {
   double* candrow_peer[kMaxDevices];             // every shard's candidate rows [2][kMaxDevices][ld]
   unsigned long long* arrive2_peer[kMaxDevices]; // every shard's arrival words of the candidate rows [2][kMaxDevices][kChainMaxWgs]
   unsigned spin_max;    // bound of every wait between workgroups / devices (polls; ~0.5-1 us each): a bug never hangs the GPU
-  int diag;             // k_block_chain2 diagnostics (LPX_CHAIN_DIAG, timing experiments only — results are wrong): bit 0 = read the
+  int diag;             // k_block_chain2 diagnostics (-DLPX_DIAG_BUILD libraries only: LPX_CHAIN_DIAG, timing experiments — results are wrong): bit 0 = read the
                         // entering column from CONTIGUOUS addresses (what a column-major mirror of the window would cost)
 };
 
@@ -1645,14 +1646,96 @@ __device__ __forceinline__ RatioRow rr_block_min2(RatioRow x, RatioRow* sh) {
   return r;
 }
 
+// ---- the pending-pivot ladder of k_block_chain2 ---------------------------------------------------------------------
+// Eight pending pivots applied in order to one value: x <- x - c[q] * r[q] (submul: product and difference rounded
+// separately, or ONE v_fma_f64 in the fused compilation).  What a step costs a lone wave per SIMD, measured
+// (scripts/micro/chain_step_cost.hip, profiles/r05_chain_step_cost_and_traces_before.txt, shader cycles per step):
+//   dependent v_fma_f64 6.6 | v_mul_f64 + v_add_f64 11.6 | + a scalar bit test and a branch NOT taken (round 4, old ring
+//   half) 22.7 | the same with the rare path inline, i.e. a branch TAKEN over it every step (round 4, own half) 36.5 |
+//   v_cmp + two v_cndmask 21.3 | s_mov exec + v_cmpx 24.9 | eight v_cmp into SGPR pairs per chunk, then s_mov exec per step 16.5.
+// So the ladder has no branch and no select: a chunk of eight steps is either `chain8` — straight multiply-adds — or
+// `chain8_from`, where a lane takes step q only if q >= stc (its start index relative to the chunk): the steps in front of
+// a lane's restart point (its row / slot was REPLACED by a pending pivot, LPState.java:139-145 / :157) are skipped by
+// EXEC.  Which of the two a chunk needs is uniform per wave (does any of its lanes start behind the chunk's first step).
+#if LPX_FUSED
+#define LPX_C2_T_OUT
+#define LPX_C2_STEP(q) "v_fma_f64 %[x], -%[c" #q "], %[r" #q "], %[x]\n\t"
+#else
+#define LPX_C2_T_OUT , [t] "=&v"(t)
+#define LPX_C2_STEP(q) "v_mul_f64 %[t], %[c" #q "], %[r" #q "]\n\tv_add_f64 %[x], %[x], -%[t]\n\t"
+#endif
+#define LPX_C2_INS                                                                                                           \
+  [c0] "v"(c[0]), [c1] "v"(c[1]), [c2] "v"(c[2]), [c3] "v"(c[3]), [c4] "v"(c[4]), [c5] "v"(c[5]), [c6] "v"(c[6]), [c7] "v"(c[7]), \
+  [r0] "v"(r[0]), [r1] "v"(r[1]), [r2] "v"(r[2]), [r3] "v"(r[3]), [r4] "v"(r[4]), [r5] "v"(r[5]), [r6] "v"(r[6]), [r7] "v"(r[7])
+__device__ __forceinline__ void chain8(double& x, const double* c, const double* r) {
+#if !LPX_FUSED
+  double t;
+#endif
+  asm volatile(LPX_C2_STEP(0) LPX_C2_STEP(1) LPX_C2_STEP(2) LPX_C2_STEP(3) LPX_C2_STEP(4) LPX_C2_STEP(5) LPX_C2_STEP(6) LPX_C2_STEP(7)
+               : [x] "+v"(x) LPX_C2_T_OUT : LPX_C2_INS);
+}
+__device__ __forceinline__ void chain8_from(double& x, const double* c, const double* r, int stc) {
+#if !LPX_FUSED
+  double t;
+#endif
+  unsigned long long sv, m0, m1, m2, m3, m4, m5, m6, m7;
+  // the eight masks under the FULL mask of the enclosing code (inactive lanes compare as 0 and stay inactive), then one
+  // s_mov exec per step; EXEC is restored before the block ends (the compiler never sees it change)
+  asm volatile("s_mov_b64 %[sv], exec\n\t"
+               "v_cmp_ge_i32 %[m0], 0, %[stc]\n\tv_cmp_ge_i32 %[m1], 1, %[stc]\n\tv_cmp_ge_i32 %[m2], 2, %[stc]\n\t"
+               "v_cmp_ge_i32 %[m3], 3, %[stc]\n\tv_cmp_ge_i32 %[m4], 4, %[stc]\n\tv_cmp_ge_i32 %[m5], 5, %[stc]\n\t"
+               "v_cmp_ge_i32 %[m6], 6, %[stc]\n\tv_cmp_ge_i32 %[m7], 7, %[stc]\n\t"
+               "s_mov_b64 exec, %[m0]\n\t" LPX_C2_STEP(0) "s_mov_b64 exec, %[m1]\n\t" LPX_C2_STEP(1)
+               "s_mov_b64 exec, %[m2]\n\t" LPX_C2_STEP(2) "s_mov_b64 exec, %[m3]\n\t" LPX_C2_STEP(3)
+               "s_mov_b64 exec, %[m4]\n\t" LPX_C2_STEP(4) "s_mov_b64 exec, %[m5]\n\t" LPX_C2_STEP(5)
+               "s_mov_b64 exec, %[m6]\n\t" LPX_C2_STEP(6) "s_mov_b64 exec, %[m7]\n\t" LPX_C2_STEP(7)
+               "s_mov_b64 exec, %[sv]"
+               : [x] "+v"(x) LPX_C2_T_OUT, [sv] "=&s"(sv), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3),
+                 [m4] "=&s"(m4), [m5] "=&s"(m5), [m6] "=&s"(m6), [m7] "=&s"(m7)
+               : LPX_C2_INS, [stc] "v"(stc));
+}
+#undef LPX_C2_INS
+#undef LPX_C2_STEP
+#undef LPX_C2_T_OUT
+// index of the highest set bit of a pair of ballots (bit u of lo = slot u, of hi = slot 64 + u), -1 if none
+__device__ __forceinline__ int top_bit(unsigned long long lo, unsigned long long hi) {
+  return hi ? 127 - __clzll((long long)hi) : (lo ? 63 - __clzll((long long)lo) : -1);
+}
+
+// Workgroup minimum of (ratio, row) WITH the winner's two payload values in ONE meeting: every wave reduces itself (DPP),
+// the lane that holds its wave's minimum writes the wave's record, the workgroup meets, every thread reads the NW records.
+// `slot` alternates from call to call: a record is rewritten two calls later, behind the meeting of the call in between.
+// (rr_block_min2 + a winner's exchange took three meetings and an LDS round trip each: 0.8-0.9 us of a decision.)
+struct MinRec {
+  double ratio, a, b;
+  int row, pad;
+};
+template <int NW>
+__device__ __forceinline__ RatioRow rr_block_min_rec(RatioRow x, double& a, double& b, MinRec (*sh)[NW], int slot) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const RatioRow w = rr_wave_min_all(x);
+  if (w.row == INT_MAX ? lane == 0 : x.row == w.row) sh[slot][wave] = MinRec{w.ratio, a, b, w.row, 0};
+  lds_barrier();
+  MinRec r = sh[slot][0];
+#pragma unroll
+  for (int k = 1; k < NW; ++k) {
+    const MinRec o = sh[slot][k];
+    if (o.ratio < r.ratio || (o.ratio == r.ratio && o.row < r.row)) r = o;
+  }
+  a = r.a;
+  b = r.b;
+  return RatioRow{r.ratio, r.row, 0};
+}
+
 constexpr int kChain2Threads = 256;
 template <int KB, int NT>
 __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   static_assert(KB == 32 || KB == 64, "ring half of 32 or 64 slots");
   static_assert(NT % 64 == 0 && NT >= 256 && NT >= 2 * KB + 64, "lanes for the pending pivots and the loader lane");
   constexpr int NC = 2 * KB / 8;   // chunks of eight pending pivots: [0, KB / 8) the previous block's, then this block's
+  constexpr int kWin = 8;          // live chunks whose ring copies a thread holds in registers at a time
   __shared__ RatioRow sh_rr[NT / 64];
-  __shared__ unsigned long long sh_mask[2];
+  __shared__ MinRec sh_rec[2][NT / 64];
   __shared__ unsigned sh_part[kChainMaxWgs * 8], sh_hand[8];
   __shared__ __attribute__((aligned(16))) double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB];
   __shared__ __attribute__((aligned(16))) int sh_e[2 * KB], sh_l[2 * KB];
@@ -1725,6 +1808,20 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     for (int u = 0; u < KB; ++u) P.own_prow[(int64_t)u * ld + j] = 0.0;
   }
   lds_barrier();
+  // Per row (column) of this thread: the LAST pending pivot that left through it (entered at it), as an index into the
+  // LDS parameters, -1 if none.  That pivot REPLACED the row's (column's) values, so the thread's chain of a later decision
+  // starts behind it (chain8_from).  Here the previous block's pivots; a decision of this launch adds its own (the
+  // owner of row l / slot e stores KB + s).  The thread's own plain stores, re-read only by itself.
+  for (int i = gid; i < m; i += T) {
+    int r = -1;
+    for (int u = 0; u < n_old; ++u) r = sh_l[u] == i ? u : r;
+    P.own_rs_a[i] = r;
+  }
+  for (int j = jfirst; j < (int)ld; j += jstep) {
+    int r = -1;
+    for (int u = 0; u < n_old; ++u) r = sh_e[u] == j ? u : r;
+    P.own_rs_b[j] = r;
+  }
 
   for (int s = 0; s < nb; ++s) {
     // ------------------------------------------------------------------ phase A: column e, ratio test
@@ -1736,33 +1833,28 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     const int r_mine = tid & (KB - 1);
     const bool old_mine = tid < KB;
     const bool valid_mine = tid < 2 * KB && (old_mine ? r_mine < n_old : r_mine < s);
-    if (tid < 2 * KB) {   // restart pivot of column e: a question to LDS only
-      const unsigned long long mask = __ballot(valid_mine && sh_e[tid] == e);
-      if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
-    }
-    lds_barrier();
-    const int ra = chain_restart<KB>(sh_mask);
-    // Which pending pivots have their OWN row among this wave's 64 rows of the first / second pass (bit u = ring slot u;
-    // all lanes are active here, lane u asks for slot u; an empty slot holds -1 and matches nothing).  A step whose bit is
-    // clear needs no "is this the pivot's row" select: the chain is then one multiply-add per step and a scalar bit test,
-    // where the select cost a compare and two v_cndmask on the dependent path of a lone wave (A.chain + B.chain: 1.0 us
-    // of a 15 us decision beside the sweep, profiles/r04_decision_chain_selects.txt).
-    unsigned long long hit_a[2][2 * KB / 64];
+    // Restart pivot of column e: the LAST pending pivot that entered at slot e left -(col / p) there (1 / p in its own
+    // row); the column restarts from it.  Every wave asks for itself (lane u looks at slot u; an empty slot holds -1 and
+    // matches nothing): a question to LDS only, no meeting.
+    int ra;
     {
-      const int row_w = (int)(blockIdx.x * NT) + (tid & ~63);
-#pragma unroll
-      for (int h = 0; h < 2 * KB / 64; ++h) {
-        const int lu = sh_l[h * 64 + (tid & 63)];
-        hit_a[0][h] = __ballot((unsigned)(lu - row_w) < 64u);
-        hit_a[1][h] = __ballot((unsigned)(lu - row_w - T) < 64u);
-      }
+      const unsigned long long lo = __ballot(sh_e[tid & 63] == e);
+      unsigned long long hi = 0;
+      if constexpr (KB == 64) hi = __ballot(sh_e[64 + (tid & 63)] == e);
+      ra = top_bit(lo, hi);
     }
     const int fo_a = ra < 0 ? 0 : (ra < KB ? ra + 1 : n_old);
     const int fn_a = ra >= KB ? ra - KB + 1 : 0;
     const bool use_b = P.b_from_tableau && s == 0;
-    // chunk c of the pending pivots: live / entirely live range tests (uniform)
-    auto first_a = [&](int c) { return c < KB / 8 ? fo_a : fn_a; };
-    auto last_of = [&](int c) { return c < KB / 8 ? n_old : s; };
+    // The LIVE chunks of the ladder in order (a chunk = eight LDS slots): the previous block's [co0, co1), then this block's
+    // [cn0, cn1) — what lies behind the restart pivot.  Under the first-positive rule the same few slots and rows come back
+    // all the time (dense random LPs: three decisions of four restart inside the last 48 pending pivots), so the live part is
+    // short; a thread holds ONE window of kWin chunks of its ring copies in registers (128 VGPRs whatever KB is — the whole
+    // ring of a 64-slot launch would be 256) and a ladder longer than that takes a second round trip for the next window.
+    const int co0_a = fo_a >> 3, co1_a = fo_a < n_old ? (n_old + 7) >> 3 : co0_a;
+    const int cn0_a = fn_a >> 3, cn1_a = fn_a < s ? (s + 7) >> 3 : cn0_a;
+    const int Lo_a = co1_a - co0_a, L_a = Lo_a + (cn1_a - cn0_a);
+    auto chunk_a = [&](int k) { return (k < Lo_a ? co0_a + k : KB / 8 + cn0_a + (k - Lo_a)) & (NC - 1); };   // LDS chunk of live chunk k
     // every load of the phase in ONE round trip; the lanes of the pending pivots first
     double pe_mine = 0.0, pc_mine = 0.0;
     const bool pe_from_rec = have_rec && tid == KB + s - 1;   // (s >= 1 whenever have_rec)
@@ -1771,26 +1863,51 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     RatioRow best = rr_none();
     double best_a = 0.0, best_b = 0.0;
     double a = 0.0, bi = 0.0, a_first = 0.0, b_first = 0.0;
-    double cv[2 * KB];   // this thread's own stores, only the chunks with a live step
+    int rs = -1;         // the row's own start index (see the launch prologue)
+    double cv[kWin * 8];   // this thread's own stores: one window of live chunks
+    auto load_window_a = [&](int i, int w0) {
+#pragma unroll
+      for (int k = 0; k < kWin; ++k) {
+        if (w0 + k < L_a) {   // (uniform)
+          const int c = chunk_a(w0 + k);
+          const char* const base = (c < KB / 8 ? oc_o : oc_n) + (uint32_t)((c * 8) & (KB - 1)) * mp8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) cv[k * 8 + q] = *reinterpret_cast<const double*>(base + ((uint32_t)q * mp8 + (uint32_t)i * 8u));
+        }
+      }
+    };
     auto load_row = [&](int i) {
       const uint32_t i8 = (uint32_t)i * 8u;   // uniform base (SGPRs) + one 32-bit lane offset per load: the rings are < 4 GiB
       // a pending pivot entered at the same slot: the column restarts from what that pivot left there, -(col / p)
       // (1 / p in its own row), computed from the thread's copy of the column as it was BEFORE that pivot
+#ifdef LPX_DIAG_BUILD
       a = ra < 0 ? ((P.diag & 1) ? A[(int64_t)(e & 7) * ld + i] : A[(int64_t)i * ld + e])
+#else
+      a = ra < 0 ? A[(int64_t)i * ld + e]
+#endif
                  : *reinterpret_cast<const double*>((ra < KB ? oc_o : oc_n) + ((uint32_t)(ra & (KB - 1)) * mp8 + i8));
       bi = use_b ? b[i] : P.own_b[i];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int r0 = (c * 8) & (KB - 1);
-        if (r0 < last_of(c) && r0 + 8 > first_a(c)) {
-#pragma unroll
-          for (int q = 0; q < 8; ++q)
-            cv[c * 8 + q] = *reinterpret_cast<const double*>((c < KB / 8 ? oc_o : oc_n) + ((uint32_t)(r0 + q) * mp8 + i8));
-        }
-      }
+      rs = P.own_rs_a[i];
+      load_window_a(i, 0);
     };
     int i = gid;
     if (i < m) load_row(i);
+    // While the loads fly: how far into the ladder does some lane of this wave start late?  reach[p] = 1 + the highest
+    // pending pivot whose OWN row is among the wave's 64 rows of pass p (lane u asks for slot u; all lanes are active
+    // here), at least ra + 1; chunks from there on are straight multiply-adds for the whole wave.
+    int reach_a[2];
+    {
+      const int row_w = (int)(blockIdx.x * NT) + (tid & ~63);
+      unsigned long long h0[2] = {0, 0}, h1[2] = {0, 0};
+#pragma unroll
+      for (int h = 0; h < 2 * KB / 64; ++h) {
+        const int lu = sh_l[h * 64 + (tid & 63)];
+        h0[h] = __ballot((unsigned)(lu - row_w) < 64u);
+        h1[h] = __ballot((unsigned)(lu - row_w - T) < 64u);
+      }
+      reach_a[0] = max(ra, top_bit(h0[0], h0[1])) + 1;
+      reach_a[1] = max(ra, top_bit(h1[0], h1[1])) + 1;
+    }
     // everything has been asked for; by the time it is here, whatever this wave stored during the previous decision has
     // long landed: the drain that makes those stores visible before this workgroup publishes anything newer is free
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1802,59 +1919,51 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     int pass_a = 0;
     while (i < m) {
       const int ig = i;
-      unsigned long long hm_a[2 * KB / 64];
-#pragma unroll
-      for (int h = 0; h < 2 * KB / 64; ++h) hm_a[h] = pass_a == 0 ? hit_a[0][h] : pass_a == 1 ? hit_a[1][h] : ~0ull;   // (later passes: every step tests)
+      const int reach = pass_a == 0 ? reach_a[0] : pass_a == 1 ? reach_a[1] : 2 * KB;   // (later passes: every chunk masked)
       ++pass_a;
-      if (ra >= 0) {   // (uniform, rare) the restart value
-        const double p_r = sh_p[ra];
-        a = (ig == sh_l[ra]) ? __ddiv_rn(1.0, p_r) : -__ddiv_rn(a, p_r);              // :139 / :157
-      }
-      // the pending pivots in order; their parameters one chunk ahead of the arithmetic, 16-byte LDS reads
+      // where this lane's chain starts, and from what: behind the later of the column's restart pivot and the row's own
+      // last pivot.  The row's own pivot rs REPLACED the row by the normalised pivot row: its entry in column e is
+      // prow_rs[e] (:139-145); otherwise the restart value -(col / p) (:157; rs == ra: the row of the restart pivot
+      // itself, 1 / p = prow_ra[e], the first case again), otherwise the tableau's entry.
+      const int st = max(ra, rs) + 1;
+      if (rs >= ra && rs >= 0) a = sh_pe[rs];
+      else if (ra >= 0) a = -__ddiv_rn(a, sh_p[ra]);                                  // :157
+      // the pending pivots in order; their parameters one chunk ahead of the arithmetic, 16-byte LDS reads.  No memory
+      // operation inside the ladder: a store there makes the compiler wait for it (vmcnt(0)) in front of the next chunk.
       double pe8[2][8];
-      // (unconditional: a chunk that is not live holds identity values, and reads under a uniform test made the
-      // compiler wait for ALL outstanding LDS reads — the NEXT chunk's included — in front of every chunk's arithmetic)
-      auto params = [&](int c) {
-        if (c < NC) {
+      double a_mid = a;   // the value between the two blocks' pivots: the entry the sweep of THIS block will read
+      auto ladder_a = [&](const int w0) {
+        auto params = [&](int k) {
+          if (k < kWin) {
+            const double* const src = &sh_pe[chunk_a(w0 + k) * 8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) pe8[c & 1][q] = sh_pe[c * 8 + q];
+            for (int q = 0; q < 8; ++q) pe8[k & 1][q] = src[q];
+          }
+        };
+        params(0);
+#pragma unroll
+        for (int k = 0; k < kWin; ++k) {
+          if (w0 + k >= L_a) break;   // (uniform) what lies behind the last pivot inside a live chunk is identity by its data
+          params(k + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          if (w0 + k == Lo_a) a_mid = a;
+          const int c8 = chunk_a(w0 + k) * 8;
+          if (__builtin_expect(c8 >= reach, 1)) chain8(a, &cv[k * 8], pe8[k & 1]);
+          else chain8_from(a, &cv[k * 8], pe8[k & 1], st - c8);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
-      params(0);
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        params(c + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c == KB / 8) P.col0[(int64_t)s * mp + i] = a;   // the entry the sweep of THIS block will read (fix-up: next kernel)
-        const int r0 = (c * 8) & (KB - 1), first = first_a(c), last = last_of(c);
-        if (r0 < last && r0 + 8 > first) {
-          if (first <= r0) {   // eight steps, no predicate: what lies behind the last pivot is identity by its data
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const double t_ = submul(a, cv[c * 8 + q], pe8[c & 1][q]);
-#ifdef LPX_CHAIN2_NOSEL   // timing experiment only (wrong in a pending pivot's own row): the chain without its selects
-              a = t_;
-#else
-              a = t_;
-              if ((hm_a[(c * 8 + q) / 64] >> ((c * 8 + q) & 63)) & 1) {   // (uniform, rare) the pivot's own row is in this wave
-                asm volatile("" ::: "memory");   // (keeps the test a scalar branch: if-converted it is the select again)
-                if (ig == sh_l[c * 8 + q]) a = pe8[c & 1][q];
-              }
-#endif
-            }
-          } else {             // (rare) a restart inside this chunk: its steps one by one, the ring value fetched again
-            const char* const oc = c < KB / 8 ? oc_o : oc_n;
-#pragma unroll 1
-            for (int u = first; u < min(last, r0 + 8); ++u) {
-              const double csu = *reinterpret_cast<const double*>(oc + ((uint32_t)u * mp8 + (uint32_t)i * 8u));
-              const double peu = sh_pe[(c < KB / 8 ? 0 : KB) + u];
-              const double t_ = submul(a, csu, peu);
-              a = (ig == sh_l[(c < KB / 8 ? 0 : KB) + u]) ? peu : t_;
-            }
-          }
+      ladder_a(0);
+      if constexpr (NC > kWin) {   // (a 64-slot launch, rare: more than kWin live chunks — a second round trip, no loop:
+        if (L_a > kWin) {          //  a loop made the compiler copy the whole window between its prologue and its body)
+          load_window_a(i, kWin);
+          ladder_a(kWin);
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      if (Lo_a >= L_a) a_mid = a;   // no pivot of this block behind the boundary
+      // (fix-up: next kernel.  A lane that starts inside this block's half stores its start value: the fix-up replaces that
+      // entry at the same pivot, whatever it held.)
+      P.col0[(int64_t)s * mp + i] = a_mid;
       LPX_C2_STAMP(9)
       st_agent(&P.col[(int64_t)s * mp + i], a);
       P.own_col[(int64_t)s * mp + i] = a;
@@ -1873,11 +1982,10 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     const double pc = from32(sh_hand[1], sh_hand[2]);   // c[e]: from the record that named e, or the loader lane
     const unsigned xtag = P.hand_base + (unsigned)s;    // sequence number of this decision (unique over launches)
     {
-      const RatioRow w = rr_block_min2(best, sh_rr);
+      double wa = best_a, wb = best_b;
+      const RatioRow w = rr_block_min_rec<NT / 64>(best, wa, wb, sh_rec, s & 1);
       LPX_C2_STAMP(11)
-      if (w.row != INT_MAX && best.row == w.row) { sh_win[0] = best_a; sh_win[1] = best_b; }
-      lds_barrier();
-      const double wa = (w.row != INT_MAX) ? sh_win[0] : 0.0, wb = (w.row != INT_MAX) ? sh_win[1] : 0.0;
+      if (w.row == INT_MAX) { wa = 0.0; wb = 0.0; }
       if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 2] = wall_clock64();
       // the workgroup's candidate as seven tagged granules — NOT behind a drain: nobody reads col_s across workgroups
       // before decision s + 1, and every wave has passed a vmcnt(0) (above) since its stores of decision s - 1
@@ -1908,18 +2016,26 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 3] = wall_clock64();
 
     // ------------------------------------------------------------------ phase B: the leaving row
+    // every WAVE reduces the workgroups' candidates for itself (a lane per candidate): no meeting, and the winner's pivot
+    // element and right-hand side come out of the winning lane by v_readlane
     RatioRow mine = rr_none();
     double mine_a = 0.0, mine_b = 0.0;
-    if (tid < G) {
-      const unsigned* q = &sh_part[tid * 8];
-      mine.ratio = from32(q[0], q[1]);
-      mine_a = from32(q[2], q[3]);
-      mine_b = from32(q[4], q[5]);
-      mine.row = (int)q[6];
+    for (int t = tid & 63; t < G; t += 64) {
+      const unsigned* q = &sh_part[t * 8];
+      const RatioRow o{from32(q[0], q[1]), (int)q[6], 0};
+      if (o.ratio < mine.ratio || (o.ratio == mine.ratio && o.row < mine.row)) {
+        mine = o;
+        mine_a = from32(q[2], q[3]);
+        mine_b = from32(q[4], q[5]);
+      }
     }
-    const RatioRow w = rr_block_min2(mine, sh_rr);
-    if (w.row != INT_MAX && tid < G && mine.row == w.row) { sh_win[0] = mine_a; sh_win[1] = mine_b; }
-    lds_barrier();
+    const RatioRow w = rr_wave_min_all(mine);
+    double win_p = 0.0, win_b = 0.0;
+    if (w.row != INT_MAX) {
+      const int wl = __ffsll((long long)__ballot(mine.row == w.row)) - 1;
+      win_p = lane_f64(mine_a, wl);
+      win_b = lane_f64(mine_b, wl);
+    }
     if (w.row == INT_MAX || !(w.ratio < kInf)) {  // getLeaving() == -1: unbounded
       if (book) {
         ctl->status = 1; ctl->do_update = 0; ctl->l = -1; ctl->ratio = w.ratio; P.up[s].do_update = 0;
@@ -1936,60 +2052,76 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     }
     LPX_C2_STAMP(12)
     const int l = w.row;
-    const double p = sh_win[0], raw_b = sh_win[1];
+    const double p = win_p, raw_b = win_b;
     if (p == 0.0) {  // ArithmeticException in the reference, LPState.java:139
       if (book) { ctl->status = 8; ctl->do_update = 0; P.up[s].do_update = 0; chain_publish(ctl, P.host_snap); }
       return;
     }
-    if (tid < 2 * KB) {   // restart pivot of row l: LDS only
-      const unsigned long long mask = __ballot(valid_mine && sh_l[tid] == l);
-      if ((tid & 63) == 0) sh_mask[tid >> 6] = mask;
-    }
-    lds_barrier();
-    const int rb = chain_restart<KB>(sh_mask);
-    // the same for the columns: which pending pivots ENTERED at one of this wave's 64 slots of the first / second pass
-    unsigned long long hit_b[2][2 * KB / 64];
+    // restart pivot of row l: the LAST pending pivot that left through row l made it its normalised pivot row; the row
+    // restarts from the thread's copy of that row (every wave asks for itself, as in phase A)
+    int rb;
     {
-      const int col_w = __builtin_amdgcn_readfirstlane(jfirst);   // (a wave's lanes own consecutive slots)
-#pragma unroll
-      for (int h = 0; h < 2 * KB / 64; ++h) {
-        const int eu = sh_e[h * 64 + (tid & 63)];
-        hit_b[0][h] = __ballot((unsigned)(eu - col_w) < 64u);
-        hit_b[1][h] = __ballot((unsigned)(eu - col_w - jstep) < 64u);
-      }
+      const unsigned long long lo = __ballot(sh_l[tid & 63] == l);
+      unsigned long long hi = 0;
+      if constexpr (KB == 64) hi = __ballot(sh_l[64 + (tid & 63)] == l);
+      rb = top_bit(lo, hi);
     }
     const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
     const int fn_b = rb >= KB ? rb - KB + 1 : 0;
-    auto first_b = [&](int c) { return c < KB / 8 ? fo_b : fn_b; };
+    const int co0_b = fo_b >> 3, co1_b = fo_b < n_old ? (n_old + 7) >> 3 : co0_b;   // the live chunks, as in phase A
+    const int cn0_b = fn_b >> 3, cn1_b = fn_b < s ? (s + 7) >> 3 : cn0_b;
+    const int Lo_b = co1_b - co0_b, L_b = Lo_b + (cn1_b - cn0_b);
+    auto chunk_b = [&](int k) { return (k < Lo_b ? co0_b + k : KB / 8 + cn0_b + (k - Lo_b)) & (NC - 1); };
     // again everything in one round trip: col_u[l] of the pending pivots first, then the thread's column of row l
     double cs_mine = 0.0;
     if (valid_mine) cs_mine = ld_agent((old_mine ? P.col_o : P.col) + (int64_t)r_mine * mp + l);
+    int32_t perm_e = 0, perm_l = 0;   // exchangeIndexes :311-320: asked for with the phase's loads (the keeper's own stores)
+    if (book) { perm_e = P.perm[e]; perm_l = P.perm[n + l]; }
     const double bl = __ddiv_rn(raw_b, p);                                         // :146
     const double inv_p = __ddiv_rn(1.0, p);                                        // :139
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
     double rec_c = 0.0, rec_pr = 0.0;   // workgroup 0: what its thread of slot j would put into the hand-off record
     const double* rowl = A + (int64_t)l * ld;
     double x = 0.0, cj = 0.0;
+    int rsb = -1;        // the column's own start index
+    auto load_window_b = [&](int j, int w0) {
+#pragma unroll
+      for (int k = 0; k < kWin; ++k) {
+        if (w0 + k < L_b) {
+          const int c = chunk_b(w0 + k);
+          const char* const base = (c < KB / 8 ? op_o : op_n) + (uint32_t)((c * 8) & (KB - 1)) * ld8;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) cv[k * 8 + q] = *reinterpret_cast<const double*>(base + ((uint32_t)q * ld8 + (uint32_t)j * 8u));
+        }
+      }
+    };
     auto load_col = [&](int j) {
       cj = ld_agent(&P.c[j]);  // this thread's own store (or the initial value)
       x = 0.0;
+      rsb = P.own_rs_b[j];
       if (j < n) {
         const uint32_t j8 = (uint32_t)j * 8u;
         x = rb < 0 ? rowl[j]
                    : *reinterpret_cast<const double*>((rb < KB ? op_o : op_n) + ((uint32_t)(rb & (KB - 1)) * ld8 + j8));
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const int r0 = (c * 8) & (KB - 1);
-          if (r0 < last_of(c) && r0 + 8 > first_b(c)) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-              cv[c * 8 + q] = *reinterpret_cast<const double*>((c < KB / 8 ? op_o : op_n) + ((uint32_t)(r0 + q) * ld8 + j8));
-          }
-        }
+        load_window_b(j, 0);
       }
     };
     int j = jfirst;
     if (j < (int)ld) load_col(j);
+    // while the loads fly, as in phase A: 1 + the highest pending pivot that ENTERED at one of this wave's 64 slots
+    int reach_b[2];
+    {
+      const int col_w = __builtin_amdgcn_readfirstlane(jfirst);   // (a wave's lanes own consecutive slots)
+      unsigned long long h0[2] = {0, 0}, h1[2] = {0, 0};
+#pragma unroll
+      for (int h = 0; h < 2 * KB / 64; ++h) {
+        const int eu = sh_e[h * 64 + (tid & 63)];
+        h0[h] = __ballot((unsigned)(eu - col_w) < 64u);
+        h1[h] = __ballot((unsigned)(eu - col_w - jstep) < 64u);
+      }
+      reach_b[0] = max(rb, top_bit(h0[0], h0[1])) + 1;
+      reach_b[1] = max(rb, top_bit(h1[0], h1[1])) + 1;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as in phase A: also the free drain of this wave's earlier stores)
     if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 4] = wall_clock64();   // this wave's loads of phase B are here
     if (valid_mine) {
@@ -2000,53 +2132,45 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     LPX_C2_STAMP(13)
     int pass_b = 0;
     while (j < (int)ld) {
-      unsigned long long hm_b[2 * KB / 64];
-#pragma unroll
-      for (int h = 0; h < 2 * KB / 64; ++h) hm_b[h] = pass_b == 0 ? hit_b[0][h] : pass_b == 1 ? hit_b[1][h] : ~0ull;
+      const int reach = pass_b == 0 ? reach_b[0] : pass_b == 1 ? reach_b[1] : 2 * KB;
       ++pass_b;
       if (j < n) {
+        // this lane's chain starts behind the later of the row's restart pivot and the LAST pending pivot that entered at
+        // slot j; that pivot left -(col[l] / p) in row l's entry of its column (:157)
+        const int st = max(rb, rsb) + 1;
+        if (rsb > rb) x = sh_dv[rsb];
         double cs8[2][8];
-        auto params = [&](int c) {   // (unconditional, as in phase A)
-          if (c < NC) {
+        double x_mid = x;   // the row as the sweep of this block will read it (fix-up)
+        auto ladder_b = [&](const int w0) {
+          auto params = [&](int k) {
+            if (k < kWin) {
+              const double* const src = &sh_cs[chunk_b(w0 + k) * 8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) cs8[c & 1][q] = sh_cs[c * 8 + q];
+              for (int q = 0; q < 8; ++q) cs8[k & 1][q] = src[q];
+            }
+          };
+          params(0);
+#pragma unroll
+          for (int k = 0; k < kWin; ++k) {
+            if (w0 + k >= L_b) break;
+            params(k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (w0 + k == Lo_b) x_mid = x;
+            const int c8 = chunk_b(w0 + k) * 8;
+            if (__builtin_expect(c8 >= reach, 1)) chain8(x, cs8[k & 1], &cv[k * 8]);
+            else chain8_from(x, cs8[k & 1], &cv[k * 8], st - c8);
+            __builtin_amdgcn_sched_barrier(0);
           }
         };
-        params(0);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          params(c + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          if (c == KB / 8) P.row0[(int64_t)s * ld + j] = x;   // the row as the sweep of this block will read it (fix-up)
-          const int r0 = (c * 8) & (KB - 1), first = first_b(c), last = last_of(c);
-          if (r0 < last && r0 + 8 > first) {
-            if (first <= r0) {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) {
-                const double t_ = submul(x, cs8[c & 1][q], cv[c * 8 + q]);
-#ifdef LPX_CHAIN2_NOSEL
-                x = t_;
-#else
-                x = t_;
-                if ((hm_b[(c * 8 + q) / 64] >> ((c * 8 + q) & 63)) & 1) {   // (uniform, rare) the pivot entered at a slot of this wave
-                  asm volatile("" ::: "memory");
-                  if (j == sh_e[c * 8 + q]) x = sh_dv[c * 8 + q];
-                }
-#endif
-              }
-            } else {           // (rare) a restart inside this chunk
-              const char* const op = c < KB / 8 ? op_o : op_n;
-#pragma unroll 1
-              for (int u = first; u < min(last, r0 + 8); ++u) {
-                const double pru = *reinterpret_cast<const double*>(op + ((uint32_t)u * ld8 + (uint32_t)j * 8u));
-                const int k = (c < KB / 8 ? 0 : KB) + u;
-                const double t_ = submul(x, sh_cs[k], pru);
-                x = (j == sh_e[k]) ? sh_dv[k] : t_;
-              }
-            }
+        ladder_b(0);
+        if constexpr (NC > kWin) {
+          if (L_b > kWin) {
+            load_window_b(j, kWin);
+            ladder_b(kWin);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
+        if (Lo_b >= L_b) x_mid = x;
+        P.row0[(int64_t)s * ld + j] = x_mid;
       }
       LPX_C2_STAMP(14)
       double cn, pr;
@@ -2059,6 +2183,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       }
       st_agent(&P.prow[(int64_t)s * ld + j], pr);
       P.own_prow[(int64_t)s * ld + j] = pr;
+      if (j == e) P.own_rs_b[j] = KB + s;   // later chains of this slot start behind pivot s
       st_agent(&P.c[j], cn);
       if (j < n && cn > kEps) {
         const RatioRow k2{P.dantzig ? -cn : 0.0, j, 0};
@@ -2076,31 +2201,40 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       // with c > eps: if there is one among them it is the answer, and the thread that owns it publishes {slot, c[slot],
       // prow_s[slot]} — all the next phase A needs of this decision — as five tagged granules, no drain.  No candidate
       // here: "none", and everybody takes the grid barrier below.
-      const RatioRow w0 = rr_block_min2(cand, sh_rr);
-      const unsigned long long tg = (unsigned long long)xtag << 32;
-      if (w0.row == INT_MAX ? tid == 0 : tid == w0.row) {
-        const bool none = w0.row == INT_MAX;
-        __hip_atomic_store(&hand[1], tg | (none ? 0u : lo32(rec_c)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&hand[2], tg | (none ? 0u : hi32(rec_c)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&hand[3], tg | (none ? 0u : lo32(rec_pr)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&hand[4], tg | (none ? 0u : hi32(rec_pr)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&hand[0], tg | (unsigned)((none ? -2 : w0.row) + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // Slots ascend with the lane and with the wave: the first lane of a wave's ballot, the first wave that has one — one
+      // meeting, no reduction.  (sh_rec[s & 1] was read by everybody several meetings ago.)
+      MinRec* const ho = sh_rec[s & 1];
+      const unsigned long long cm = __ballot(cand.row != INT_MAX);
+      if ((tid & 63) == (cm ? __ffsll((long long)cm) - 1 : 0)) ho[tid >> 6] = MinRec{rec_c, rec_pr, 0.0, cm ? cand.row : -1, 0};
+      lds_barrier();
+      if (tid < 5) {
+        int slot = -1;
+        double hc = 0.0, hp = 0.0;
+#pragma unroll
+        for (int k = NT / 64 - 1; k >= 0; --k) {
+          const MinRec o = ho[k];
+          if (o.row >= 0) { slot = o.row; hc = o.ratio; hp = o.a; }
+        }
+        const unsigned d = tid == 0 ? (unsigned)((slot < 0 ? -2 : slot) + 2) : slot < 0 ? 0u : tid == 1 ? lo32(hc) : tid == 2 ? hi32(hc) : tid == 3 ? lo32(hp) : hi32(hp);
+        __hip_atomic_store(&hand[tid], ((unsigned long long)xtag << 32) | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 5] = wall_clock64();   // workgroup 0: the hand-off record is on its way
     // the row owners add pivot s to b (kept with every decided pivot applied) — after the columns, so that workgroup 0
     // publishes the entering slot first
+    // (the owner of row l also notes that later chains of this row start behind pivot s)
     if (gid < m) P.own_b[gid] = (gid == l) ? bl : submul(b_first, a_first, bl);      // :146 / :164
+    if (gid == l) P.own_rs_a[l] = KB + s;
     for (int i2 = gid + T; i2 < m; i2 += T) {
       const double colv = P.own_col[(int64_t)s * mp + i2];
       const double bcur = use_b ? b[i2] : P.own_b[i2];
       P.own_b[i2] = (i2 == l) ? bl : submul(bcur, colv, bl);
+      if (i2 == l) P.own_rs_a[l] = KB + s;
     }
     if (tid == 0) { sh_e[KB + s] = e; sh_l[KB + s] = l; sh_p[KB + s] = p; sh_bl[KB + s] = bl; }
     if (book) {
       v = addmul(v, bl, pc);                                                       // :171
-      const int32_t perm_e = P.perm[e], perm_l = P.perm[n + l];                    // exchangeIndexes :311-320
-      P.perm[e] = perm_l;
+      P.perm[e] = perm_l;                                                          // exchangeIndexes :311-320
       P.perm[n + l] = perm_e;
       if (track >= 0) {                                                            // LPSolver.java:151-155
         if (e == track) track = l + n;
@@ -4532,14 +4666,17 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
   P.own_col_o = R.chain_own_col + oo * R.mp; P.own_prow_o = R.chain_own_prow + oo * B.ld;
   P.own_dvc_o = R.chain_own_dvc + oo * R.mp; P.up_o = R.up + oo;
   P.n_old = n_old; P.own_b = R.chain_own_b; P.b_from_tableau = b_from_tableau; P.nb = nb;
+  P.own_rs_a = R.chain_own_rs; P.own_rs_b = R.chain_own_rs + R.mp;
   P.partA = reinterpret_cast<ChainPart*>(R.chain_part_a); P.partB = reinterpret_cast<RatioRow*>(R.chain_part_b);
   P.bar = R.chain_bar + 32 * (seq & 1); P.bar_next = R.chain_bar + 32 * ((seq + 1) & 1);
   P.hand = reinterpret_cast<unsigned long long*>(R.chain_bar + 64);   // its own 128-byte line
   P.hand_base = (unsigned)(seq + 1) * 64u;  // > any sequence of earlier launches (<= kBlockMax decisions each)
   P.dantzig = dantzig; P.fences = fences; P.host_snap = host_snap; P.dbg = trace ? R.chain_dbg : nullptr;
   P.spin_max = (mg && mg->spin_max) ? mg->spin_max : (1u << 22);
-  static const int chain_diag = getenv("LPX_CHAIN_DIAG") ? atoi(getenv("LPX_CHAIN_DIAG")) : 0;   // timing experiments only
+#ifdef LPX_DIAG_BUILD   // timing experiments only (results are wrong): never in the release library
+  static const int chain_diag = getenv("LPX_CHAIN_DIAG") ? atoi(getenv("LPX_CHAIN_DIAG")) : 0;
   P.diag = chain_diag;
+#endif
   P.census = R.census;
   if (mg) {
     P.shard_row0 = mg->row0; P.m_global = mg->m_global; P.n_dev = mg->n_dev; P.dev = mg->dev;
@@ -4808,7 +4945,11 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
   hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, s, R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
                      R.tickets, nstrips_full * 8, R.clk, two_waves ? 1 : 0);
   if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
-    static const int a_mask = getenv("LPX_SWEEP_DIAG") && atoi(getenv("LPX_SWEEP_DIAG")) == 1 ? 0 : -1;   // timing experiments only
+#ifdef LPX_DIAG_BUILD   // timing experiments only (every tile reads tile 0's multipliers: results are wrong): never in the release library
+    static const int a_mask = getenv("LPX_SWEEP_DIAG") && atoi(getenv("LPX_SWEEP_DIAG")) == 1 ? 0 : -1;
+#else
+    const int a_mask = -1;
+#endif
     const int ng2 = nstrips_full * 4;
     const int G2 = std::max(1, std::min(ntiles, 2 * slots / std::max(1, ng2)));
     const dim3 grid2(ng2 * G2), block2(256);
