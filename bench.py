@@ -49,8 +49,11 @@ FP64_VALU_PEAK_TFLOPS = 39.3
 CHUNK = 1024
 
 
+MFMA_KERNELS = ("k_sweep64_mfma", "k_sweep64_mfma2")
+
+
 def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traffic=None, traffic_source=None,
-                   fused=False, clock_mhz=0):
+                   fused=False, clock_mhz=0, cus=0):
     """The bounded roofline figure of one row-update / sweep launch.
     One launch reads and writes every fp64 entry once (16*m*n bytes — counter-verified, profiles/) and issues, per entry
     and pivot it applies, TWO fp64 instructions (v_mul_f64 + v_add_f64: the default arithmetic rounds the product and the
@@ -61,8 +64,11 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
     (`clock_ghz`: in-kernel s_memtime against the 100 MHz counter, lpx_state_info.sweep_clock_mhz; nominal when it was not
     measured): under the 1400 W package cap an fp64-dense sweep runs at 1.5-2.0 GHz and the instruction term is then the
     larger one long before it is at 2.4 GHz.  `cycles_per_launch` = launch time x that clock (a kernel at its
-    instruction-issue floor costs the same cycles whatever the clock).  `pivot_equiv_frac` keeps SURVEY 8(d)'s per-PIVOT
-    figure (16*m*n bytes per pivot / 8 TB/s), which exceeds 1 when one sweep applies several pivots."""
+    instruction-issue floor costs the same cycles whatever the clock).  The instruction term of `bound` is taken on the CUs
+    the sweep's stream really has (`cus`: lpx_state_info.sweep_cus — in the overlapped loop the decisions keep 4 or 8 CUs
+    per XCD to themselves); on the matrix cores (k_sweep64_mfma2: fp64 MFMA rate = fp64 vector rate on MI355X) the name
+    is "fp64_mfma".  `pivot_equiv_frac` keeps SURVEY 8(d)'s per-PIVOT figure (16*m*n bytes per pivot / 8 TB/s), which
+    exceeds 1 when one sweep applies several pivots."""
     if not launches or not (avg_ms > 0):
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
                 "traffic_source": traffic_source, "kernel": kernel, "launches_sampled": launches}
@@ -73,10 +79,13 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
     t_hbm = bytes_moved / (HBM_PEAK_GBS * 1e9)
     t_valu = flops / (FP64_VALU_PEAK_TFLOPS * 1e12)
     clock_ghz = clock_mhz / 1e3 if clock_mhz and clock_mhz > 0 else None
-    t_valu_clk = flops / (256 * 4 * 16 * clock_ghz * 1e9) if clock_ghz else t_valu
+    ncu = int(cus) if cus and cus > 0 else 256
+    t_valu_clk = flops / (ncu * 4 * 16 * (clock_ghz or 2.4) * 1e9)   # on the sweep's CUs, at the clock held
     hbm_peak_bound = t_hbm >= t_valu                  # which data-sheet peak `frac` / `achieved` are quoted against
-    out = {"bound": "hbm" if t_hbm >= t_valu_clk else "fp64_valu",
-           "bound_at": "measured clock" if clock_ghz else "nominal clock (not measured)",
+    fp64_name = "fp64_mfma" if fused and kernel in MFMA_KERNELS else "fp64_valu"
+    out = {"bound": "hbm" if t_hbm >= t_valu_clk else fp64_name,
+           "bound_at": ("measured clock" if clock_ghz else "nominal clock (not measured)") + ", %d CUs" % ncu,
+           "cus": ncu,
            "achieved": bytes_moved / t / 1e9 if hbm_peak_bound else flops / t / 1e12,
            "peak": HBM_PEAK_GBS if hbm_peak_bound else FP64_VALU_PEAK_TFLOPS,
            "unit": "GB/s" if hbm_peak_bound else "T fp64 instr/s",
@@ -89,7 +98,8 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
                           else "two roundings (v_mul_f64 + v_add_f64 per entry and pivot)"),
            "clock_ghz": clock_ghz,
            "cycles_per_launch": t * clock_ghz * 1e9 if clock_ghz else None,
-           "lower_bound_ms": {"hbm": 1e3 * t_hbm, "fp64_valu": 1e3 * t_valu, "fp64_valu_at_clock": 1e3 * t_valu_clk},
+           "lower_bound_ms": {"hbm": 1e3 * t_hbm, "fp64_valu": 1e3 * t_valu, "fp64_valu_at_clock": 1e3 * t_valu_clk,
+                              "fp64_on_its_cus_at_clock": 1e3 * t_valu_clk},
            "hbm_GBps": bytes_moved / t / 1e9, "hbm_frac": t_hbm / t,
            "fp64_valu_Tinstr": flops / t / 1e12, "fp64_valu_frac": t_valu / t,
            "fp64_valu_frac_at_clock": t_valu_clk / t,
@@ -297,8 +307,9 @@ def main():
                     help="N=1, cfg4: skip the `steady` object (the default loop for --steady-steps pivots after "
                          "--steady-warmup, cfg4 and cfg3, added when the headline run itself is shorter than that)")
     ap.add_argument("--no-fused", action="store_true",
-                    help="N=1, cfg4: skip the `steady_fused` object (the steady-state protocol on fresh handles in the opt-in "
-                         "fused-arithmetic mode, cfg4 and cfg3, replayed on the oracle's fused instantiation)")
+                    help="N=1, cfg4: skip the `steady_plain` (`steady_fused`) object: the steady-state protocol on fresh handles "
+                         "in the arithmetic mode the library did NOT choose by size, cfg4 and cfg3, replayed on the matching "
+                         "oracle instantiation")
     ap.add_argument("--no-onepass", action="store_true",
                     help="skip the `onepass` object: the bandwidth-bound schedule north_star describes (one tableau pass "
                          "per pivot at N=1; two pivots per pass, the smallest block of the multi-GPU handle, at every N)")
@@ -402,6 +413,13 @@ def main():
         k, v = kv.split("=", 1)
         options[k] = int(v)
 
+    def is_fused(inf):
+        """the arithmetic a handle really computes in (lpx_state_info.arith_fused: LPX_OPT_FUSED resolved — by size unless
+        the --option set says otherwise), which picks the oracle instantiation that replays it"""
+        if isinstance(inf, dict) and "arith_fused" in inf:
+            return bool(inf["arith_fused"])
+        return options.get("fused", 0) == 1
+
     def run_single(Aw, bw, cw, mw, nw, steps=None, warmup=None, st=None, done=0, opts=None):
         """warm-up + timed region of the single-GPU device loop on one workload; returns the measurements.
         st: continue on this handle (it has done `done` pivots) instead of uploading the tableau again.
@@ -437,7 +455,7 @@ def main():
         avg_ms = kernel_ms / launches if launches else float("nan")
         return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms, "steps": Ks,
                 "warmup": Ws, "done": done + Ws + Ks, "pivots_per_launch": pivots_per_launch, "upload_s": t_up,
-                "info": st.info(), "fused": bool(st.get_option("fused"))}
+                "info": st.info(), "fused": bool(st.info().get("arith_fused", 0))}
 
     def measured(r, mw, nw, name, Aw, bw, cw, with_parity):
         """one measurement as an object of the JSON line: value, roofline of its sweep / row-update launch, oracle replay"""
@@ -447,7 +465,8 @@ def main():
              "value": r["steps"] / r["elapsed"], "unit": "pivots/s", "ms_per_step": 1e3 * r["elapsed"] / r["steps"],
              "steps": r["steps"], "warmup": r["warmup"], "pivots_per_sweep": r["block"],
              "roofline": roofline_block(mw, nw, r["pivots_per_launch"], r["avg_ms"], kern, r["launches"], traffic, tsrc,
-                                        fused=r.get("fused", False), clock_mhz=(r.get("info") or {}).get("sweep_clock_mhz", 0)),
+                                        fused=r.get("fused", False), clock_mhz=(r.get("info") or {}).get("sweep_clock_mhz", 0),
+                                        cus=(r.get("info") or {}).get("sweep_cus", 0)),
              "loop_bound": loop_bound(1e3 * r["elapsed"] / r["steps"], r["pivots_per_launch"], r["avg_ms"], r.get("info"))}
         if with_parity:
             o["parity_after_timed_region"] = parity_after(r["st"], Aw, bw, cw, r["done"], mw, nw, host_cores(),
@@ -568,7 +587,7 @@ def main():
                 if not args.no_parity:
                     grid_leg["parity_after_timed_region"] = parity_after(m2, Aw, bw, cw, 64 + int(piv4), m, n, host_cores(),
                                                                          args.parity_max_pivots,
-                                                                         fused=bool(options.get("fused", 0)))
+                                                                         fused=is_fused(m2.info()))
             except Exception as ex:   # noqa: BLE001
                 grid_leg = {"error": "%s: %s" % (type(ex).__name__, ex)}
             finally:
@@ -715,7 +734,8 @@ def main():
                                ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline)))},
             "roofline": roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel_label(block, info), launches,
                                        *load_traffic(args.workload, world, block, kernel_label(block, info)),
-                                       fused=bool(options.get("fused", 0)), clock_mhz=(info or {}).get("sweep_clock_mhz", 0)),
+                                       fused=is_fused(info), clock_mhz=(info or {}).get("sweep_clock_mhz", 0),
+                                       cus=(info or {}).get("sweep_cus", 0)),
             "loop_bound": loop_bound(1e3 * elapsed / K, pivots_per_launch, avg_ms, info),
             "objective_after_timed_region": objective,
             "host_gen_s": t_gen,
@@ -731,7 +751,7 @@ def main():
             # (on the multi-GPU handle the bandwidth-bound leg has run behind the timed region: the replay covers it too)
             line["parity_after_timed_region"] = parity_after(st, A, b, c, r1_.get("pivots_done", W + K) if peer else W + K,
                                                              m, n, host_cores(), args.parity_max_pivots,
-                                                             fused=bool(options.get("fused", 0)))
+                                                             fused=is_fused(info))
         line["devices_visible"] = torch.cuda.device_count()
         if peer and r1_.get("onepass") is not None:
             line["onepass"] = r1_["onepass"]
@@ -762,11 +782,14 @@ def main():
                             st=r_first["st"], done=r_first["done"])
             return measured(rs, mw, nw, name, Aw, bw, cw, with_parity), rs["done"]
 
+        default_fused = is_fused(info)   # what the library chose for this workload (LPX_OPT_FUSED = 2: by size)
+
         def fused_leg(Aw, bw, cw, mw, nw, name, block=None):
-            """The same steady-state protocol on a FRESH handle in the opt-in fused-arithmetic mode (LPX_OPT_FUSED: every
-            update one v_fma_f64 — or, in blocks of 33..64, four of them per v_mfma_f64_16x16x4), replayed on the oracle's
-            fused instantiation.  block: pivots per sweep (None: by size)."""
-            fo = dict(options, fused=1)
+            """The same steady-state protocol on a FRESH handle in the OTHER arithmetic mode than the one the headline ran
+            in: with the by-size default (fused multiply-add updates from 0.5 GiB: one v_fma_f64 per update — or, in blocks
+            of 33..64, four of them per v_mfma_f64_16x16x4) that is the opt-out, LPX_OPT_FUSED = 0 (product and difference
+            rounded separately); replayed on the matching oracle instantiation.  block: pivots per sweep (None: by size)."""
+            fo = dict(options, fused=0 if default_fused else 1)
             if block is not None:
                 fo["block"] = block
             rf = run_single(Aw, bw, cw, mw, nw, steps=args.steady_steps, warmup=args.steady_warmup, opts=fo)
@@ -775,7 +798,7 @@ def main():
             finally:
                 rf["st"].close()
 
-        want_fused = want_steady and not args.no_fused and not options.get("fused", 0)
+        want_fused = want_steady and not args.no_fused and "fused" not in options
         steady_fused = {}
         done_total = W + K          # pivots the cfg4 handle has done (every leg below continues on it)
         if want_steady:
@@ -806,7 +829,7 @@ def main():
                         "ms_per_step": 1e3 * dt / max(1, piv2),
                         "roofline": roofline_block(m, n, piv2 / float(ln) if ln else float("nan"),
                                                    kms / ln if ln else float("nan"), kernel_label(block_opt, inf), ln,
-                                                   fused=bool(options.get("fused", 0)))}
+                                                   fused=is_fused(inf), cus=inf.get("sweep_cus", 0))}
             try:
                 line["onepass"] = dict(one_leg(2, args.onepass_steps), one_pass_per_pivot=one_leg(1, args.onepass_steps // 2))
             except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
@@ -818,7 +841,7 @@ def main():
             # ONE replay of everything the cfg4 handle has done: headline, steady leg, one-pass legs (k_update_tiles<2> and
             # k_update at full height are checked here too)
             final = parity_after(st, A, b, c, done_total, m, n, host_cores(), args.parity_max_pivots,
-                                 fused=bool(options.get("fused", 0)))
+                                 fused=is_fused(info))
             final["covers"] = "warm-up + steps, the steady leg and the one-pass legs: every pivot this handle has done"
             if "cfg4" in steady:
                 steady["cfg4"]["parity_after_timed_region"] = final
@@ -831,11 +854,6 @@ def main():
                 steady_fused["cfg4"] = fused_leg(A, b, c, m, n, "cfg4")
             except Exception as ex:   # noqa: BLE001 - the extra leg never breaks the line
                 steady_fused["cfg4"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-            try:   # the same with blocks of 32 (k_sweep32_pull, one v_fma_f64 per entry and pivot): the by-size choice
-                   # above is blocks of 64 on the matrix cores
-                steady_fused["cfg4_block32"] = fused_leg(A, b, c, m, n, "cfg4", block=32)
-            except Exception as ex:   # noqa: BLE001
-                steady_fused["cfg4_block32"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         if single and args.workload == "cfg4" and not args.no_cfg3:
             # BASELINE.md quotes its single-GPU roofline target on cfg3 (m=8192, n=16384): measure it in the same
             # run, same protocol, as an extra object (the headline `value` above stays the cfg4 job)
@@ -860,11 +878,11 @@ def main():
                                   % (args.steady_warmup, args.steady_steps))
             line["steady"] = steady
         if steady_fused:
-            steady_fused["protocol"] = ("a fresh handle with option fused = 1 (LPX_OPT_FUSED: every update x - c*r one "
-                                        "v_fma_f64; opt-in, `value` and `steady` are the default two-rounding arithmetic): "
-                                        "%d warm-up pivots, then %d timed pivots; replayed on the oracle's fused "
-                                        "instantiation" % (args.steady_warmup, args.steady_steps))
-            line["steady_fused"] = steady_fused
+            steady_fused["protocol"] = ("a fresh handle in the other arithmetic mode (option fused = %d; `value` and `steady` "
+                                        "run in the library's by-size choice, lpx_state_info.arith_fused = %d): %d warm-up "
+                                        "pivots, then %d timed pivots; replayed on the matching oracle instantiation"
+                                        % (0 if default_fused else 1, int(default_fused), args.steady_warmup, args.steady_steps))
+            line["steady_plain" if default_fused else "steady_fused"] = steady_fused
         if world == 1 and not peer and not args.no_cpu_baseline:
             rows_s = min(m, 8192)
             line.update(cpu_baselines(A[:rows_s], b[:rows_s], c, m, args.cpu_budget_s))

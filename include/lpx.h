@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define LPX_ABI_VERSION 4
+#define LPX_ABI_VERSION 5
 
 /* Status codes.  One per exception message of the reference; the host shim maps them back
  * to the exact exception class + message because the reference's tests assert on the text. */
@@ -142,7 +142,7 @@ typedef enum lpx_option {
   LPX_OPT_MULTI_ONEHOP = 15,  /* lpx_multi: 1 = every shard ships its candidate's row with its candidate (one cross-device hop per decision instead of two); 0 (default) = candidates, then the winner's normalised row */
   LPX_OPT_SWEEP_CUS = 16,     /* overlapped loop: CUs of the sweep stream's mask (multiple of 8; 0 = all but the decisions'); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
   LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16; other values are rounded down to a multiple of 4 but never below 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
-  LPX_OPT_FUSED = 18,         /* arithmetic of the updates x - c*r (LPState.java:162, :164, :177) and v + b*c (:171): 0 (default) = product and difference rounded separately, as the reference rounds them; 1 = one fused multiply-add each.  Every kernel of the handle switches together; set it before the first pivot of a solve (the two modes give different bits, so a switch in mid-solve matches neither checker) */
+  LPX_OPT_FUSED = 18,         /* arithmetic of the updates x - c*r (LPState.java:162, :164, :177) and v + b*c (:171): 0 = product and difference rounded separately, as the reference rounds them (bit-identical to the unfused fp64 oracle); 1 = one fused multiply-add each (bit-identical to the oracle's fused instantiation); 2 (default) = by size: fused on an unsharded tableau of 0.5 GiB and more, where it is 5-75 % faster, otherwise 0.  Both binary modes leave the decimal-15 pivot sequence of the reference equally often (tests/golden/divergence_census.json).  lpx_state_info.arith_fused reports the mode in effect.  Every kernel of the handle switches together; set it before the first pivot of a solve (the two modes give different bits, so a switch in mid-solve matches neither checker) */
   LPX_OPT_CHAIN_FORM = 19,    /* decision kernel of the one-device blocked loop: 0 = k_block_chain_t (round 2/3), 1 = k_block_chain2_t (round 4: a phase asks for everything at once, nothing is drained on the critical path, workgroups of 512) */
   LPX_OPT_COUNT = 20
 } lpx_option;
@@ -167,7 +167,8 @@ typedef struct lpx_state_info {
   int32_t multi_onehop;         /* lpx_multi: 1 = the last decision launches used the one-hop exchange              */
   int32_t sweep_clock_mhz;      /* shader clock the chip held over the last k_sweep32_pull / k_sweep64_pull launch (in-kernel
                                    s_memtime against the 100 MHz counter, probes in the launches around it); 0 = not measured */
-  int32_t reserved[2];
+  int32_t sweep_cus;            /* CUs the stream of the last blocked sweep could use (all of them outside the overlapped loop) */
+  int32_t arith_fused;          /* arithmetic in effect (LPX_OPT_FUSED resolved): 0 = two roundings per update, 1 = fused multiply-add */
 } lpx_state_info;
 int lpx_state_get_info(lpx_state* s, lpx_state_info* out);
 /* Name of a lpx_state_info.sweep_kernel code as rocprofv3 prints it ("k_sweep32_dma", "k_update_tiles", ...; "" = none). */
@@ -313,8 +314,8 @@ typedef struct lpx_solve_options {
   int32_t restore_order_len;    /* entries of restore_order; < 0: n (every original variable has a name).  With a
                                  * non-NULL restore_order, 0 means NO variable is substituted (an empty keySet());
                                  * a NULL restore_order selects the default-name order over all n variables          */
-  int32_t fused;                /* LPX_OPT_FUSED for the handle(s) of this solve: 0 = two roundings per update (default),
-                                 * 1 = fused multiply-add updates                                                     */
+  int32_t fused;                /* arithmetic of the handle(s) of this solve: 0 = the library's choice by size (LPX_OPT_FUSED = 2),
+                                 * 1 = fused multiply-add updates, -1 = two roundings per update (the opt-out)         */
   int32_t reserved;
 } lpx_solve_options;
 

@@ -20,19 +20,20 @@ OPTIONS = {"block": 0, "chain": 1, "overlap": 2, "overlap_serial": 3, "overlap_m
            "fused": 18, "chain_form": 19}
 
 # Arithmetic of the handles the host classes create when the caller does not say (option "fused" / LPSolver(fused=...)):
-# False = the default of the library (product and difference of every update rounded separately, as the reference rounds
-# them), True = fused multiply-add updates (LPX_OPT_FUSED).  See set_default_arithmetic().
-DEFAULT_FUSED = False
+# None = the library's choice (LPX_OPT_FUSED = 2: by size — fused multiply-add updates on an unsharded tableau of 0.5 GiB
+# and more, otherwise product and difference of every update rounded separately, as the reference rounds them),
+# False = always the two roundings, True = always fused.  See set_default_arithmetic().
+DEFAULT_FUSED = None
 
 
 def set_default_arithmetic(mode):
-    """"plain" (default) or "fused": what LPState / LPMulti / LPSolver / HipShardEngine select for new handles unless told
-    otherwise.  Returns the previous mode."""
+    """"auto" (the library's choice by size; default), "plain" or "fused": what LPState / LPMulti / LPSolver /
+    HipShardEngine select for new handles unless told otherwise.  Returns the previous mode."""
     global DEFAULT_FUSED
-    if mode not in ("plain", "fused"):
-        raise ValueError('arithmetic mode is "plain" or "fused"')
-    prev = "fused" if DEFAULT_FUSED else "plain"
-    DEFAULT_FUSED = mode == "fused"
+    if mode not in ("auto", "plain", "fused"):
+        raise ValueError('arithmetic mode is "auto", "plain" or "fused"')
+    prev = "auto" if DEFAULT_FUSED is None else "fused" if DEFAULT_FUSED else "plain"
+    DEFAULT_FUSED = None if mode == "auto" else mode == "fused"
     return prev
 
 
@@ -61,7 +62,7 @@ class StateInfo(C.Structure):
     _fields_ = [(k, C.c_int32) for k in (
         "block", "chain_wgs", "chain_wgs_requested", "chain_resident_max", "chain_blocks_per_cu",
         "chain_stream_masked", "chain_xcd_mask", "sweep_xcd_mask", "overlapped", "nontemporal", "sweep_rows",
-        "sweep_kernel", "multi_onehop", "sweep_clock_mhz", "reserved1", "reserved2")]
+        "sweep_kernel", "multi_onehop", "sweep_clock_mhz", "sweep_cus", "arith_fused")]
 
 
 class SolveOptions(C.Structure):

@@ -78,7 +78,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_MULTI_ONEHOP", 0, 0, 1},          // LPX_OPT_MULTI_ONEHOP
     {"LPX_SWEEP_CUS", 0, 0, 256},           // LPX_OPT_SWEEP_CUS
     {"LPX_CHAIN_CUS", 0, 0, 16},            // LPX_OPT_CHAIN_CUS
-    {"LPX_FUSED", 0, 0, 1},                 // LPX_OPT_FUSED
+    {"LPX_FUSED", 2, 0, 2},                 // LPX_OPT_FUSED
     {"LPX_CHAIN_FORM", 1, 0, 1},            // LPX_OPT_CHAIN_FORM
 };
 
@@ -96,6 +96,18 @@ static const int64_t* env_defaults() {
   }();
   (void)once;
   return d;
+}
+
+// LPX_OPT_FUSED resolved.  By size (2): the fused multiply-add pays where the sweep is the bound — measured, same box,
+// pivots/s fused / plain: 512 MiB 81.2k / 76.9k (+5.6 %), 768 MiB 69.4k / 63.4k, cfg3 (1 GiB) 60.6k / 51.5k, cfg4 29.9k / 16.8k
+// (profiles/r05_by_size_arith_grid.txt; 256 MiB and below: +2 % or less, profiles/r04_block_by_size_small.txt) — and it is no less faithful to the decimal
+// reference than the two-rounding form (tests/golden/divergence_census.json: both leave the decimal-15 pivot sequence on
+// the same 116 of 408 LPs, the 6-decimal result never differs).  Shards keep the plain arithmetic unless told.
+void resolve_arithmetic(lpx_state* s) {
+  const int64_t v = s->opt[LPX_OPT_FUSED];
+  const double bytes = 8.0 * (double)s->m * (double)s->B.ld;
+  const bool by_size = s->m == s->m_global && !s->multi_shard && bytes >= 0.5 * 1073741824.0;
+  s->B.fused = v == 1 || (v == 2 && by_size);
 }
 
 // Tiling of k_update.
@@ -232,7 +244,7 @@ int alloc_state(int32_t m_local, int32_t n, int32_t n_cap, int32_t row0, int32_t
   const int64_t mp = std::max<int64_t>(2, round_up(m_local, 2)) + 2;
   s->B.ld = ld;
   memcpy(s->opt, env_defaults(), sizeof s->opt);
-  s->B.fused = s->opt[LPX_OPT_FUSED] != 0;
+  resolve_arithmetic(s);
   s->B.chain_form = (int)s->opt[LPX_OPT_CHAIN_FORM];
   apply_layout_options(s);
 #define ALLOC(ptr, count, type)                                                            \
@@ -668,6 +680,7 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
   // CUs the sweep's stream may use: all but the decisions' reserved ones on the masked overlap stream
   const int cus = (stream == s->ov_sweep && s->ov_masked) ? s->ov_sweep_cus : device_cus(s);
   int kernel_used = 0;
+  s->info.sweep_cus = cus;
   s->info.sweep_rows = lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, (int)s->opt[LPX_OPT_SWEEP_ROWS],
                                                 s->nontemporal, stream, A_src, b_src,
                                                 sample ? s->ev[s->ev_used + 1] : nullptr, cus,
@@ -982,7 +995,7 @@ extern "C" int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value) {
     return fail(LPX_BAD_ARGUMENT, "lpx_state_set_option: the CU-masked stream pair of this handle exists already (set CHAIN_CUS / SWEEP_CUS before the first blocked loop)");
   s->opt[key] = value;
   if (key == LPX_OPT_CHAIN_FORM) s->B.chain_form = (int)value;
-  if (key == LPX_OPT_FUSED) s->B.fused = value != 0;   // which of the two compilations of the kernels the launches take
+  if (key == LPX_OPT_FUSED) resolve_arithmetic(s);   // which of the two compilations of the kernels the launches take
   if (key == LPX_OPT_UPDATE_U || key == LPX_OPT_UPDATE_ROWS || key == LPX_OPT_NT) apply_layout_options(s);
   return 0;
 }
@@ -999,6 +1012,7 @@ extern "C" int lpx_state_get_info(lpx_state* s, lpx_state_info* out) {
   if (!s || !out) return fail(LPX_BAD_ARGUMENT, "lpx_state_get_info: NULL argument");
   HIP_TRY(hipSetDevice(s->device));
   s->info.block = choose_block(s);
+  s->info.arith_fused = s->B.fused ? 1 : 0;
   s->info.chain_xcd_mask = 0;
   s->info.sweep_xcd_mask = 0;
   if (s->R.census) {
@@ -1043,9 +1057,9 @@ extern "C" int lpx_debug_read_census(lpx_state* s, uint32_t* out, int32_t count)
 
 // stamps per decision the decision kernel of this handle writes: k_block_chain_t 5, k_block_chain2_t 8
 #ifdef LPX_CHAIN2_FINE
-static int chain_trace_stride(const lpx_state* s) { return (s->B.chain_form == 1 && !s->multi_shard) ? 16 : 5; }
+static int chain_trace_stride(const lpx_state* s) { return (s->B.chain_form == 1 && !(s->multi_shard && s->opt[LPX_OPT_MULTI_ONEHOP] != 0)) ? 16 : 5; }
 #else
-static int chain_trace_stride(const lpx_state* s) { return (s->B.chain_form == 1 && !s->multi_shard) ? 8 : 5; }
+static int chain_trace_stride(const lpx_state* s) { return (s->B.chain_form == 1 && !(s->multi_shard && s->opt[LPX_OPT_MULTI_ONEHOP] != 0)) ? 8 : 5; }
 #endif
 
 extern "C" int lpx_state_read_chain_trace(lpx_state* s, int64_t* ticks, int32_t cap, int32_t* ndecisions) {

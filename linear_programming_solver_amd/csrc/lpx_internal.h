@@ -95,6 +95,7 @@ int upload_common(lpx_state* s, const double* A, int64_t lda, const double* b, c
                   const int32_t* perm, hipMemcpyKind kind);
 void init_ctl(lpx_state* s, double v);
 int set_running(lpx_state* s, int64_t max_pivots, int32_t track);
+void resolve_arithmetic(lpx_state* s);      // LPX_OPT_FUSED (0 / 1 / 2 = by size) -> Buffers::fused
 int ensure_block_ring(lpx_state* s);
 int ensure_spare_tableau(lpx_state* s);     // the second tableau / b of the out-of-place forms
 int ensure_overlap_streams(lpx_state* s);   // ov_chain / ov_sweep (CU-masked when possible) and their events

@@ -1728,7 +1728,13 @@ __device__ __forceinline__ RatioRow rr_block_min_rec(RatioRow x, double& a, doub
 }
 
 constexpr int kChain2Threads = 256;
-template <int KB, int NT>
+// MG: the shards of an lpx_multi (row blocks on several devices, see "multi-device decisions" above).  The two-hop exchange
+// of k_block_chain_t on this kernel's shorter path: after the workgroups of a device have agreed on the device's candidate,
+// its first thread stores it into every device's mailbox and every WAVE reduces the mailbox of its own device; the shard
+// that owns the leaving row computes the normalised row, stores it into every peer's replica of the ring as it goes and
+// raises its workgroups' arrival words behind a drain; the other shards wait for those words and read the row from their
+// replica.  Everything replicated (c, v, perm, the hand-off of workgroup 0) is computed on every device, identically.
+template <int KB, int NT, bool MG>
 __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   static_assert(KB == 32 || KB == 64, "ring half of 32 or 64 slots");
   static_assert(NT % 64 == 0 && NT >= 256 && NT >= 2 * KB + 64, "lanes for the pending pivots and the loader lane");
@@ -1748,6 +1754,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
 #define LPX_C2_STAMP(k)
 #define LPX_C2_STRIDE 8
 #endif
+  const int row0 = MG ? P.shard_row0 : 0;   // global index of local row 0 (the ring's parameter blocks name GLOBAL rows)
   const double* __restrict__ A = P.A;
   const double* __restrict__ b = P.b;
   const int64_t ld = P.ld, mp = P.mp;
@@ -1814,7 +1821,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   // owner of row l / slot e stores KB + s).  The thread's own plain stores, re-read only by itself.
   for (int i = gid; i < m; i += T) {
     int r = -1;
-    for (int u = 0; u < n_old; ++u) r = sh_l[u] == i ? u : r;
+    for (int u = 0; u < n_old; ++u) r = sh_l[u] == row0 + i ? u : r;
     P.own_rs_a[i] = r;
   }
   for (int j = jfirst; j < (int)ld; j += jstep) {
@@ -1858,7 +1865,10 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     // every load of the phase in ONE round trip; the lanes of the pending pivots first
     double pe_mine = 0.0, pc_mine = 0.0;
     const bool pe_from_rec = have_rec && tid == KB + s - 1;   // (s >= 1 whenever have_rec)
-    if (valid_mine && !pe_from_rec) pe_mine = ld_agent((old_mine ? P.prow_o : P.prow) + (int64_t)r_mine * ld + e);
+    if (valid_mine && !pe_from_rec) {   // (on a shard: possibly stored by a peer device)
+      const double* const pe_src = (old_mine ? P.prow_o : P.prow) + (int64_t)r_mine * ld + e;
+      pe_mine = MG ? ld_sys(pe_src) : ld_agent(pe_src);
+    }
     if (tid == NT - 1 && !have_rec) pc_mine = ld_agent(&P.c[e]);
     RatioRow best = rr_none();
     double best_a = 0.0, best_b = 0.0;
@@ -1897,7 +1907,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     // here), at least ra + 1; chunks from there on are straight multiply-adds for the whole wave.
     int reach_a[2];
     {
-      const int row_w = (int)(blockIdx.x * NT) + (tid & ~63);
+      const int row_w = row0 + (int)(blockIdx.x * NT) + (tid & ~63);
       unsigned long long h0[2] = {0, 0}, h1[2] = {0, 0};
 #pragma unroll
       for (int h = 0; h < 2 * KB / 64; ++h) {
@@ -1918,7 +1928,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     LPX_C2_STAMP(8)
     int pass_a = 0;
     while (i < m) {
-      const int ig = i;
+      const int ig = row0 + i;   // global row
       const int reach = pass_a == 0 ? reach_a[0] : pass_a == 1 ? reach_a[1] : 2 * KB;   // (later passes: every chunk masked)
       ++pass_a;
       // where this lane's chain starts, and from what: behind the later of the column's restart pivot and the row's own
@@ -2029,12 +2039,58 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
         mine_b = from32(q[4], q[5]);
       }
     }
-    const RatioRow w = rr_wave_min_all(mine);
+    RatioRow w = rr_wave_min_all(mine);
     double win_p = 0.0, win_b = 0.0;
     if (w.row != INT_MAX) {
       const int wl = __ffsll((long long)__ballot(mine.row == w.row)) - 1;
       win_p = lane_f64(mine_a, wl);
       win_b = lane_f64(mine_b, wl);
+    }
+    if constexpr (MG) {
+      // allreduce(min+loc) over the shards: this shard's winner goes into slot `dev` of every device's mailbox (the two
+      // slots alternate with the decisions of the whole LOOP, see k_block_chain_t), then every wave reduces the n_dev
+      // records of its own device's mailbox (lowest global row wins ties, LPState.java:292-303)
+      const int mslot = (P.mail_slot0 + s) & 1;
+      if (lead) {
+        for (int d = 0; d < P.n_dev; ++d) {
+          MgMail* rec = &P.mail_peer[d][mslot * kMaxDevices + P.dev];
+          st_sys(&rec->ratio, w.ratio);
+          st_sys(&rec->a, win_p);
+          st_sys(&rec->bi, win_b);
+          __hip_atomic_store(&rec->row, w.row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (P.fences & 1) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        for (int d = 0; d < P.n_dev; ++d)
+          __hip_atomic_store(&P.mail_peer[d][mslot * kMaxDevices + P.dev].tag, xtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      RatioRow theirs = rr_none();
+      double theirs_a = 0.0, theirs_b = 0.0;
+      if ((tid & 63) < P.n_dev) {
+        const MgMail* rec = &P.mail_peer[P.dev][mslot * kMaxDevices + (tid & 63)];
+        unsigned spins = 0;
+        while (__hip_atomic_load(&rec->tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != xtag) {
+          LPX_BARRIER_SLEEP;
+          if (++spins > P.spin_max) { sh_fail = 2 + 16 * (tid & 63); break; }   // 2: a peer's candidate record
+        }
+        if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        theirs.ratio = ld_sys(&rec->ratio);
+        theirs.row = __hip_atomic_load(&rec->row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        theirs_a = ld_sys(&rec->a);
+        theirs_b = ld_sys(&rec->bi);
+      }
+      w = rr_wave_min_all(theirs);
+      win_p = 0.0; win_b = 0.0;
+      if (w.row != INT_MAX) {
+        const int wl = __ffsll((long long)__ballot(theirs.row == w.row)) - 1;
+        win_p = lane_f64(theirs_a, wl);
+        win_b = lane_f64(theirs_b, wl);
+      }
+      lds_barrier();   // (sh_fail of another wave)
+      if (sh_fail) { if (book) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
     }
     if (w.row == INT_MAX || !(w.ratio < kInf)) {  // getLeaving() == -1: unbounded
       if (book) {
@@ -2066,22 +2122,42 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       if constexpr (KB == 64) hi = __ballot(sh_l[64 + (tid & 63)] == l);
       rb = top_bit(lo, hi);
     }
+    // On shards only the device that holds row l computes it; the others receive the normalised row (below).
+    const bool owner = !MG || (l >= row0 && l < row0 + m);
+    const int ll = l - row0;   // local index of the leaving row on its owner
     const int fo_b = rb < 0 ? 0 : (rb < KB ? rb + 1 : n_old);
     const int fn_b = rb >= KB ? rb - KB + 1 : 0;
     const int co0_b = fo_b >> 3, co1_b = fo_b < n_old ? (n_old + 7) >> 3 : co0_b;   // the live chunks, as in phase A
     const int cn0_b = fn_b >> 3, cn1_b = fn_b < s ? (s + 7) >> 3 : cn0_b;
-    const int Lo_b = co1_b - co0_b, L_b = Lo_b + (cn1_b - cn0_b);
+    const int Lo_b = owner ? co1_b - co0_b : 0, L_b = owner ? Lo_b + (cn1_b - cn0_b) : 0;
     auto chunk_b = [&](int k) { return (k < Lo_b ? co0_b + k : KB / 8 + cn0_b + (k - Lo_b)) & (NC - 1); };
     // again everything in one round trip: col_u[l] of the pending pivots first, then the thread's column of row l
     double cs_mine = 0.0;
-    if (valid_mine) cs_mine = ld_agent((old_mine ? P.col_o : P.col) + (int64_t)r_mine * mp + l);
+    if (valid_mine && owner) cs_mine = ld_agent((old_mine ? P.col_o : P.col) + (int64_t)r_mine * mp + ll);
     int32_t perm_e = 0, perm_l = 0;   // exchangeIndexes :311-320: asked for with the phase's loads (the keeper's own stores)
     if (book) { perm_e = P.perm[e]; perm_l = P.perm[n + l]; }
     const double bl = __ddiv_rn(raw_b, p);                                         // :146
     const double inv_p = __ddiv_rn(1.0, p);                                        // :139
     RatioRow cand = rr_none();  // (key, slot): key 0 = first slot (reference), -c = largest coefficient (Dantzig)
     double rec_c = 0.0, rec_pr = 0.0;   // workgroup 0: what its thread of slot j would put into the hand-off record
-    const double* rowl = A + (int64_t)l * ld;
+    const double* rowl = A + (int64_t)(owner ? ll : 0) * ld;
+    if constexpr (MG) {
+      if (!owner) {
+        // wait until every workgroup of the owner has stored its columns of the normalised row into THIS device's replica
+        // of the ring (one arrival word per owner workgroup, raised after its stores have drained)
+        if (tid < G) {
+          const unsigned long long* aw = &P.arrive_peer[P.dev][tid];
+          unsigned spins = 0;
+          while (__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != (unsigned long long)xtag) {
+            LPX_BARRIER_SLEEP;
+            if (++spins > P.spin_max) { sh_fail = 3 + 16 * tid; break; }   // 3: the owner's arrival word
+          }
+          if (P.fences & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        }
+        lds_barrier();
+        if (sh_fail) { if (book) { ctl->status = 7; ctl->reserved = sh_fail + 1000 * s; chain_publish(ctl, P.host_snap); } return; }
+      }
+    }
     double x = 0.0, cj = 0.0;
     int rsb = -1;        // the column's own start index
     auto load_window_b = [&](int j, int w0) {
@@ -2099,7 +2175,9 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       cj = ld_agent(&P.c[j]);  // this thread's own store (or the initial value)
       x = 0.0;
       rsb = P.own_rs_b[j];
-      if (j < n) {
+      if (!owner) {   // (shards) the owner's value, from this device's replica of the ring
+        x = (j < n && j != e) ? ld_sys(&P.prow[(int64_t)s * ld + j]) : 0.0;
+      } else if (j < n) {
         const uint32_t j8 = (uint32_t)j * 8u;
         x = rb < 0 ? rowl[j]
                    : *reinterpret_cast<const double*>((rb < KB ? op_o : op_n) + ((uint32_t)(rb & (KB - 1)) * ld8 + j8));
@@ -2134,7 +2212,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     while (j < (int)ld) {
       const int reach = pass_b == 0 ? reach_b[0] : pass_b == 1 ? reach_b[1] : 2 * KB;
       ++pass_b;
-      if (j < n) {
+      if (j < n && owner) {
         // this lane's chain starts behind the later of the row's restart pivot and the LAST pending pivot that entered at
         // slot j; that pivot left -(col[l] / p) in row l's entry of its column (:157)
         const int st = max(rb, rsb) + 1;
@@ -2178,8 +2256,14 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
         pr = inv_p;
         cn = -__ddiv_rn(pc, p);                                                    // :172
       } else {
-        pr = __ddiv_rn(x, p);                                                      // :144
+        pr = owner ? __ddiv_rn(x, p) : x;                                          // :144 (shards: the owner's value)
         cn = submul(cj, pc, pr);                                                   // :177
+      }
+      if constexpr (MG) {
+        if (owner) {   // broadcast: the value goes into every other device's replica of the ring
+          for (int d = 0; d < P.n_dev; ++d)
+            if (d != P.dev) st_sys(&P.prow_peer[d][(int64_t)s * ld + j], pr);
+        }
       }
       st_agent(&P.prow[(int64_t)s * ld + j], pr);
       P.own_prow[(int64_t)s * ld + j] = pr;
@@ -2219,17 +2303,32 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
         __hip_atomic_store(&hand[tid], ((unsigned long long)xtag << 32) | d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    if constexpr (MG) {
+      if (owner && P.n_dev > 1) {   // this workgroup's columns are on their way to every peer: drain, meet, signal
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        if (tid == 0) {
+          if (P.fences & 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          for (int d = 0; d < P.n_dev; ++d)
+            if (d != P.dev)
+              __hip_atomic_store(&P.arrive_peer[d][blockIdx.x], (unsigned long long)xtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
     if (P.dbg && lead) P.dbg[s * LPX_C2_STRIDE + 5] = wall_clock64();   // workgroup 0: the hand-off record is on its way
     // the row owners add pivot s to b (kept with every decided pivot applied) — after the columns, so that workgroup 0
     // publishes the entering slot first
     // (the owner of row l also notes that later chains of this row start behind pivot s)
-    if (gid < m) P.own_b[gid] = (gid == l) ? bl : submul(b_first, a_first, bl);      // :146 / :164
-    if (gid == l) P.own_rs_a[l] = KB + s;
+    if (gid < m) P.own_b[gid] = (row0 + gid == l) ? bl : submul(b_first, a_first, bl);      // :146 / :164
+    if (gid < m && row0 + gid == l) P.own_rs_a[gid] = KB + s;
     for (int i2 = gid + T; i2 < m; i2 += T) {
       const double colv = P.own_col[(int64_t)s * mp + i2];
       const double bcur = use_b ? b[i2] : P.own_b[i2];
-      P.own_b[i2] = (i2 == l) ? bl : submul(bcur, colv, bl);
-      if (i2 == l) P.own_rs_a[l] = KB + s;
+      P.own_b[i2] = (row0 + i2 == l) ? bl : submul(bcur, colv, bl);
+      if (row0 + i2 == l) P.own_rs_a[i2] = KB + s;
     }
     if (tid == 0) { sh_e[KB + s] = e; sh_l[KB + s] = l; sh_p[KB + s] = p; sh_bl[KB + s] = bl; }
     if (book) {
@@ -4256,8 +4355,8 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
   }
   __shared__ double sh_p[kBlockMax], sh_bl[kBlockMax];
   __shared__ __attribute__((aligned(16))) double sh_x[kBlockMax][kFixChunk];   // job 0: prow_r[e_s]; job 1: col_r[l_s]   (r: all pivots, s: this chunk's)
-  __shared__ int sh_e[kBlockMax], sh_l[kBlockMax], sh_eq[kBlockMax];
-  __shared__ int sh_np;
+  __shared__ int sh_e[kBlockMax], sh_l[kBlockMax], sh_eq[kBlockMax], sh_pick[kBlockMax + kFixChunk];
+  __shared__ int sh_np, sh_npick;
   const int s0 = blockIdx.y * kFixChunk, job = blockIdx.z;
   // (the grid is max(m, ld) wide for all three jobs: a workgroup with nothing to do leaves before the ring is looked at)
   if ((int64_t)blockIdx.x * blockDim.x >= (job == 1 ? ld : (int64_t)m_local) || (job == 2 && s0 != 0)) return;
@@ -4272,18 +4371,40 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
     sh_bl[threadIdx.x] = live ? q.bl : 0.0;
   }
   __syncthreads();
+  // Pivots that share their entering slot (their leaving row) end in the SAME column (row): a later pivot at the slot
+  // restarts the column whatever it held (:157), a later pivot through the row replaces the row (:139-145).  So only the
+  // LAST pivot of every slot (row) is a chain here — under the first-positive rule a block of 64 pivots touches 10-15
+  // distinct slots and rows (three decisions of four come back to a slot of the last 48), i.e. a quarter of the chains
+  // and of the scattered column writes.
+  if (job != 2 && threadIdx.x < 64) {
+    const int q = threadIdx.x;
+    const int key = job == 1 ? sh_l[q] : sh_e[q];
+    bool keep = q < np;
+    for (int r = q + 1; r < np; ++r) keep = keep && (job == 1 ? sh_l[r] : sh_e[r]) != key;
+    const unsigned long long mask = __ballot(keep);
+    if (keep) sh_pick[__popcll(mask & ((1ull << q) - 1ull))] = q;
+    const int npick = __popcll(mask);
+    if (q < kFixChunk) sh_pick[npick + q] = 0;   // (padding of the last chunk: reads stay inside the ring)
+    if (q == 0) sh_npick = npick;
+  }
+  __syncthreads();
+  const int npick = job == 2 ? 0 : sh_npick;
+  if (job != 2 && s0 >= npick) return;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int ns = min(kFixChunk, np - s0);   // pivots of this chunk (job 0 / 1)
+  const int ns = min(kFixChunk, npick - s0);   // chains of this chunk (job 0 / 1)
+  int pk[kFixChunk];                         // their pivots
+#pragma unroll
+  for (int q = 0; q < kFixChunk; ++q) pk[q] = sh_pick[(job == 2 ? 0 : s0) + q];
   const int lane = threadIdx.x & 63;
   const int t_wave = t - lane;              // the wave's first row (job 0, 2) / column (job 1)
   if (job == 0) {  // entering columns of pending pivots s0 .. s0 + ns - 1, all local rows
     for (int idx = threadIdx.x; idx < np * kFixChunk; idx += blockDim.x) {
       const int r = idx / kFixChunk, q = idx % kFixChunk;
-      sh_x[r][q] = q < ns ? prow_ring[(int64_t)r * ld + sh_e[s0 + q]] : 0.0;
+      sh_x[r][q] = q < ns ? prow_ring[(int64_t)r * ld + sh_e[sh_pick[s0 + q]]] : 0.0;
     }
     if ((int)threadIdx.x < np) {   // which chains of the chunk entered at pivot r's slot (the division of :157)
       int mask = 0;
-      for (int q = 0; q < ns; ++q) mask |= (sh_e[s0 + q] == sh_e[threadIdx.x]) << q;
+      for (int q = 0; q < ns; ++q) mask |= (sh_e[sh_pick[s0 + q]] == sh_e[threadIdx.x]) << q;
       sh_eq[threadIdx.x] = mask;
     }
     __syncthreads();
@@ -4292,7 +4413,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
     if (t < m_local) {
       double v[kFixChunk];
 #pragma unroll
-      for (int q = 0; q < kFixChunk; ++q) v[q] = q < ns ? col0_ring[(int64_t)(s0 + q) * mp + t] : 0.0;
+      for (int q = 0; q < kFixChunk; ++q) v[q] = q < ns ? col0_ring[(int64_t)pk[q] * mp + t] : 0.0;
       // the ring values of eight steps are requested together (they do not depend on the running values), one batch
       // ahead of the arithmetic that uses them
       double cv[8], cvn[8];
@@ -4330,17 +4451,17 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
       }
 #pragma unroll
       for (int q = 0; q < kFixChunk; ++q)
-        if (q < ns) A[(int64_t)t * ld + sh_e[s0 + q]] = v[q];
+        if (q < ns) A[(int64_t)t * ld + sh_e[pk[q]]] = v[q];
     }
   } else if (job == 1) {  // pivot rows of pending pivots s0 .. (those that live on this shard), all columns
     for (int idx = threadIdx.x; idx < np * kFixChunk; idx += blockDim.x) {
       const int r = idx / kFixChunk, q = idx % kFixChunk;
-      const int i = q < ns ? sh_l[s0 + q] : -1;
+      const int i = q < ns ? sh_l[sh_pick[s0 + q]] : -1;
       sh_x[r][q] = (i >= 0 && i < m_local) ? col_ring[(int64_t)r * mp + i] : 0.0;
     }
     if ((int)threadIdx.x < np) {   // which chains of the chunk left through pivot r's row (row := normalised row)
       int mask = 0;
-      for (int q = 0; q < ns; ++q) mask |= (sh_l[s0 + q] == sh_l[threadIdx.x]) << q;
+      for (int q = 0; q < ns; ++q) mask |= (sh_l[sh_pick[s0 + q]] == sh_l[threadIdx.x]) << q;
       sh_eq[threadIdx.x] = mask;
     }
     __syncthreads();
@@ -4349,7 +4470,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
     if (t < (int)ld) {
       double v[kFixChunk];
 #pragma unroll
-      for (int q = 0; q < kFixChunk; ++q) v[q] = (q < ns && t < n) ? row0_ring[(int64_t)(s0 + q) * ld + t] : 0.0;
+      for (int q = 0; q < kFixChunk; ++q) v[q] = (q < ns && t < n) ? row0_ring[(int64_t)pk[q] * ld + t] : 0.0;
       double pv[8], pvn[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) pv[u] = (u < np) ? prow_ring[(int64_t)u * ld + t] : 0.0;
@@ -4385,7 +4506,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
       }
 #pragma unroll
       for (int q = 0; q < kFixChunk; ++q) {
-        const int i = q < ns ? sh_l[s0 + q] : -1;
+        const int i = q < ns ? sh_l[pk[q]] : -1;
         if (i >= 0 && i < m_local) A[(int64_t)i * ld + t] = v[q];
       }
     }
@@ -4647,8 +4768,10 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
   // chain_form 1 (one device): k_block_chain2, workgroups of kChain2Threads — one row / one column per thread needs
   // fewer of them (+1: workgroup 0 serves the hand-off window only); never more than the caller found resident (wgs
   // counts workgroups of ONE per CU, which holds for both kernels)
-  const bool form2 = mg == nullptr && B.chain_form == 1;
-  if (form2) {
+  // (shards: the two-hop exchange is grafted onto k_block_chain2 too; the opt-in one-hop form keeps k_block_chain_t.  Their
+  // grid is the caller's, identical on every device — a shard waits for one arrival word per workgroup of the owner)
+  const bool form2 = B.chain_form == 1 && (mg == nullptr || !mg->onehop);
+  if (form2 && mg == nullptr) {
     const int64_t rows_wgs = (m + kChain2Threads - 1) / kChain2Threads;
     const int64_t cols_wgs = (std::max<int64_t>(B.ld - 256, 0) + kChain2Threads - 1) / kChain2Threads + 1;
     G = (int)std::max<int64_t>(1, std::min<int64_t>(G, std::max(rows_wgs, cols_wgs)));
@@ -4689,12 +4812,15 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
       P.candrow_peer[d] = mg->candrow[d];
       P.arrive2_peer[d] = mg->arrive2[d];
     }
-    if (wide) hipLaunchKernelGGL((k_block_chain_t<true, 64>), dim3(G), dim3(256), 0, s, P);
+    if (form2) {
+      if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, true>), dim3(G), dim3(kChain2Threads), 0, s, P);
+      else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, true>), dim3(G), dim3(kChain2Threads), 0, s, P);
+    } else if (wide) hipLaunchKernelGGL((k_block_chain_t<true, 64>), dim3(G), dim3(256), 0, s, P);
     else hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(G), dim3(256), 0, s, P);
   } else if (form2) {
     P.m_global = m; P.n_dev = 1;
-    if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads>), dim3(G), dim3(kChain2Threads), 0, s, P);
-    else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads>), dim3(G), dim3(kChain2Threads), 0, s, P);
+    if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, false>), dim3(G), dim3(kChain2Threads), 0, s, P);
+    else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, false>), dim3(G), dim3(kChain2Threads), 0, s, P);
   } else {
     P.m_global = m; P.n_dev = 1;
     if (wide) hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(G), dim3(256), 0, s, P);
@@ -4790,8 +4916,9 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
   hipLaunchKernelGGL((k_block_chain_t<false, 32>), dim3(1), dim3(256), 0, s, P);
   hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(1), dim3(256), 0, s, P);
   hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(1), dim3(256), 0, s, P);
-  hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads>), dim3(1), dim3(kChain2Threads), 0, s, P);
-  hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads>), dim3(1), dim3(kChain2Threads), 0, s, P);
+  hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, false>), dim3(1), dim3(kChain2Threads), 0, s, P);
+  hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, false>), dim3(1), dim3(kChain2Threads), 0, s, P);
+  hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, true>), dim3(1), dim3(kChain2Threads), 0, s, P);
   (void)hipGetLastError();
 }
 
@@ -4801,7 +4928,7 @@ int chain_blocks_per_cu() {
   int n2 = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_block_chain_t<true, 32>), 256, 0) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, (k_block_chain_t<false, 64>), 256, 0) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (k_block_chain2_t<64, kChain2Threads>), kChain2Threads, 0) != hipSuccess) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (k_block_chain2_t<64, kChain2Threads, true>), kChain2Threads, 0) != hipSuccess) {
     (void)hipGetLastError();
     nb = nw = n2 = 1;
   }

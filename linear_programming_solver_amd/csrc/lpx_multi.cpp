@@ -103,6 +103,7 @@ int multi_create(int32_t m, int32_t n, int32_t n_cap, const double* A, int64_t l
     M->sh[r] = s;
     s->peer_written = M->distinct_devices;
     s->multi_shard = true;
+    resolve_arithmetic(s);   // (the by-size choice of the fused arithmetic is for unsharded handles)
     if (int rc = upload_common(s, A ? A + (int64_t)r0 * lda : nullptr, lda, b ? b + r0 : nullptr, c ? c : czero.data(), v,
                                perm, hipMemcpyHostToDevice)) {
       multi_free(M);

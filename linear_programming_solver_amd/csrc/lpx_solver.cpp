@@ -213,8 +213,8 @@ extern "C" int lpx_solve(int32_t m, int32_t n, const double* A, int64_t lda, con
   if (o.pricing != 0) {
     if (int rc = lpx_state_set_pricing(s, o.pricing)) { res->status = rc; return rc; }
   }
-  if (o.fused != 0) {
-    if (int rc = lpx_state_set_option(s, LPX_OPT_FUSED, 1)) { res->status = rc; return rc; }
+  if (o.fused != 0) {   // 1: fused multiply-add updates, -1: two roundings per update (0: the library's choice by size)
+    if (int rc = lpx_state_set_option(s, LPX_OPT_FUSED, o.fused > 0 ? 1 : 0)) { res->status = rc; return rc; }
   }
   hipStream_t st = stream(s);
   lpxk::Buffers& B = buffers(s);
@@ -553,7 +553,7 @@ extern "C" int lpx_solve_multi(int32_t m, int32_t n, const double* A, int64_t ld
     if (int rc = lpx_multi_set_pricing(M, o.pricing)) { res->status = rc; return rc; }
   }
   if (o.fused != 0) {
-    if (int rc = lpx_multi_set_option(M, LPX_OPT_FUSED, 1)) { res->status = rc; return rc; }
+    if (int rc = lpx_multi_set_option(M, LPX_OPT_FUSED, o.fused > 0 ? 1 : 0)) { res->status = rc; return rc; }
   }
   double t_pivots = 0.0;
   int status = LPX_OPTIMAL;

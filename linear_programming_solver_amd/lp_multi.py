@@ -35,8 +35,8 @@ class LPMulti:
                 raise_for_status(rc)
         if block is not None:
             self.set_option("block", block)
-        if _lib.DEFAULT_FUSED and "fused" not in (options or {}):
-            self.set_option("fused", 1)
+        if _lib.DEFAULT_FUSED is not None and "fused" not in (options or {}):
+            self.set_option("fused", int(_lib.DEFAULT_FUSED))
         for key, value in (options or {}).items():
             self.set_option(key, value)
 

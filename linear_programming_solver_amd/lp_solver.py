@@ -36,13 +36,17 @@ class LPSolver:
         pricing="dantzig": opt-in largest-coefficient rule (same optimum, ~10x fewer pivots, no pivot parity).
         devices=[d0, d1, ...]: solve with the row blocks of the tableau on several GPUs (lpx_solve_multi).
         fused=True: every update x - c*r as one fused multiply-add (LPX_OPT_FUSED; one binary rounding where the
-        reference has two decimal ones, LPState.java:162 — checked against the oracle's fused instantiation)."""
+        reference has two decimal ones, LPState.java:162 — checked against the oracle's fused instantiation);
+        fused=False: product and difference rounded separately; None: the library's choice by size (fused from 0.5 GiB)."""
         self.fused = _lib.DEFAULT_FUSED if fused is None else bool(fused)
         self.device = int(device)
         self.devices = None if devices is None else [int(d) for d in devices]
         self.max_pivots = int(max_pivots)
         self.pricing = _lib.PRICING[pricing]
         self.last = None
+
+    def _arith_options(self):
+        return {} if self.fused is None else {"fused": int(self.fused)}
 
     def solve(self, st_form, restore_order=None):
         """LPSolver.solve(stForm).  Unlike the reference this never modifies `st_form` (the reference
@@ -57,7 +61,7 @@ class LPSolver:
         opts.has_variable_names = 1 if st_form.has_variable_names() else 0
         opts.max_pivots = self.max_pivots
         opts.pricing = self.pricing
-        opts.fused = 1 if self.fused else 0
+        opts.fused = 0 if self.fused is None else (1 if self.fused else -1)
         order = None
         if restore_order is not None:
             order = np.ascontiguousarray(np.asarray(restore_order, dtype=np.int32))
@@ -142,9 +146,9 @@ class LPSolver:
                 variables[st_form.n + i] = nm
                 coefficients[nm] = st_form.n + i
             return LPState(st_form.A, st_form.b, st_form.c, 0.0, variables, coefficients, st_form.m, st_form.n,
-                           device=self.device, options={"fused": int(self.fused)})
+                           device=self.device, options=self._arith_options())
         return LPState(st_form.A, st_form.b, st_form.c, 0.0, None, None, st_form.m, st_form.n, device=self.device,
-                       options={"fused": int(self.fused)})
+                       options=self._arith_options())
 
     def convert_into_aux_lp(self, st_form):
         """LPSolver.convertIntoAuxLP (LPSolver.java:283-321): extra column of -1, objective -x0, x0 named by
@@ -165,7 +169,7 @@ class LPSolver:
             variables[n + 1 + i] = nm
             coefficients[nm] = n + 1 + i
         return LPState(auxA, st_form.b, auxc, 0.0, variables, coefficients, m, n + 1, device=self.device,
-                       options={"fused": int(self.fused)})
+                       options=self._arith_options())
 
     def restore_initial_lp(self, aux_lp, initial, index_of_x0, restore_order=None):
         """LPSolver.restoreInitialLP (LPSolver.java:200-246), in place on the auxiliary LPState `aux_lp`, which

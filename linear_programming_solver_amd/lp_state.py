@@ -51,8 +51,8 @@ class LPState:
             rc = L.lpx_state_set_block(h, int(block))
             if rc:
                 raise_for_status(rc)
-        if _lib.DEFAULT_FUSED and "fused" not in (options or {}):
-            self.set_option("fused", 1)
+        if _lib.DEFAULT_FUSED is not None and "fused" not in (options or {}):
+            self.set_option("fused", int(_lib.DEFAULT_FUSED))
         for key, value in (options or {}).items():
             self.set_option(key, value)
 

@@ -60,8 +60,9 @@ class HipShardEngine:
             rc = L.lpx_state_set_pricing(h, _lib.PRICING[pricing])
             if rc:
                 raise_for_status(rc)
-        if _lib.DEFAULT_FUSED if fused is None else fused:   # fused multiply-add updates (LPX_OPT_FUSED), every rank alike
-            rc = L.lpx_state_set_option(h, _lib.OPTIONS["fused"], 1)
+        want = _lib.DEFAULT_FUSED if fused is None else bool(fused)
+        if want is not None:   # every rank alike (None: the library's choice — shards keep the two roundings per update)
+            rc = L.lpx_state_set_option(h, _lib.OPTIONS["fused"], int(want))
             if rc:
                 raise_for_status(rc)
         dev = torch.device("cuda", self.device)

@@ -15,7 +15,7 @@ if "cfg3" in j:
     print(tag, "cfg3", round(j["cfg3"]["value"], 1), "pivots/s sweep", round((r3.get("avg_kernel_ms") or 0) * 1e3, 1),
           "us frac", None if r3["frac"] is None else round(r3["frac"], 3), "parity",
           (j["cfg3"].get("parity_after_timed_region") or {}).get("ok"))
-for group in ("steady", "steady_fused"):
+for group in ("steady", "steady_plain", "steady_fused"):
   for name, leg in (j.get(group) or {}).items():
     if not isinstance(leg, dict) or "roofline" not in leg:
         if isinstance(leg, dict):

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lpxlib):
     for name in names:
         assert hasattr(L, name), "liblpx.so does not export " + name
         assert name in bound, "python binding misses " + name
-    assert L.lpx_abi_version() == 4
+    assert L.lpx_abi_version() == 5
 
 
 def test_status_messages_match_reference_text(lpxlib):

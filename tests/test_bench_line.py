@@ -18,11 +18,17 @@ def test_roofline_block_is_bounded_and_names_the_binding_term():
     # one there (2 m n K / (256 x 4 x 16 x 1.56 GHz) = 1.345 ms > 1.074 ms) although `frac` stays quoted against the
     # data-sheet peaks; cycles per launch = time x clock
     rc = bench.roofline_block(32768, 16384, 32, 1.80, "k_sweep32_pull", 16, clock_mhz=1560)
-    assert rc["bound"] == "fp64_valu" and rc["bound_at"] == "measured clock" and math.isclose(rc["frac"], r["frac"] * 1.72 / 1.80)
+    assert rc["bound"] == "fp64_valu" and rc["bound_at"] == "measured clock, 256 CUs" and math.isclose(rc["frac"], r["frac"] * 1.72 / 1.80)
     assert math.isclose(rc["cycles_per_launch"], 1.80e-3 * 1.56e9) and 1.34 < rc["lower_bound_ms"]["fp64_valu_at_clock"] < 1.35
     # fused arithmetic: one instruction per entry and pivot, the memory pass binds again at that clock
     rf = bench.roofline_block(32768, 16384, 32, 1.54, "k_sweep32_pull", 16, fused=True, clock_mhz=1900)
     assert rf["bound"] == "hbm" and 0.69 < rf["frac"] < 0.70 and rf["arithmetic"].startswith("fused")
+    # blocks of 64 on the matrix cores beside the decisions (round 4's driver record: 1.898 ms at 2.048 GHz on the 192 CUs
+    # the decisions leave): 16 x 64 cycles per 16 x 16 tile = m n 64 lane-operations on 192 x 4 SIMDs = 1.365 ms > the memory
+    # pass (1.074 ms): the matrix pipe binds, although on all 256 CUs it would not (Weak 4)
+    rm = bench.roofline_block(32768, 16384, 64, 1.898, "k_sweep64_mfma2", 8, fused=True, clock_mhz=2048, cus=192)
+    assert rm["bound"] == "fp64_mfma" and rm["cus"] == 192 and 1.36 < rm["lower_bound_ms"]["fp64_on_its_cus_at_clock"] < 1.37
+    assert bench.roofline_block(32768, 16384, 64, 1.898, "k_sweep64_mfma2", 8, fused=True, clock_mhz=2048)["bound"] == "hbm"
     # nothing sampled: no fraction is invented
     assert bench.roofline_block(8192, 16384, 32, float("nan"), "k", 0)["frac"] is None
 
