@@ -143,7 +143,7 @@ typedef enum lpx_option {
   LPX_OPT_SWEEP_CUS = 16,     /* overlapped loop: CUs of the sweep stream's mask (multiple of 8; 0 = all but the decisions'); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
   LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16; other values are rounded down to a multiple of 4 but never below 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
   LPX_OPT_FUSED = 18,         /* arithmetic of the updates x - c*r (LPState.java:162, :164, :177) and v + b*c (:171): 0 = product and difference rounded separately, as the reference rounds them (bit-identical to the unfused fp64 oracle); 1 = one fused multiply-add each (bit-identical to the oracle's fused instantiation); 2 (default) = by size: fused on an unsharded tableau of 0.5 GiB and more, where it is 5-75 % faster, otherwise 0.  Both binary modes leave the decimal-15 pivot sequence of the reference equally often (tests/golden/divergence_census.json).  lpx_state_info.arith_fused reports the mode in effect.  Every kernel of the handle switches together; set it before the first pivot of a solve (the two modes give different bits, so a switch in mid-solve matches neither checker) */
-  LPX_OPT_CHAIN_FORM = 19,    /* decision kernel of the one-device blocked loop: 0 = k_block_chain_t (round 2/3), 1 = k_block_chain2_t (round 4: a phase asks for everything at once, nothing is drained on the critical path, workgroups of 512) */
+  LPX_OPT_CHAIN_FORM = 19,    /* decision kernel of the blocked loop: 0 = k_block_chain_t (round 2/3), 1 (default) = k_block_chain2_t (round 4/5: a phase asks for everything at once, nothing is drained on the critical path, branch-free pending-pivot ladder; workgroups of 256 threads; also on the shards of an lpx_multi unless LPX_OPT_MULTI_ONEHOP is set) */
   LPX_OPT_COUNT = 20
 } lpx_option;
 int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value);
@@ -165,8 +165,9 @@ typedef struct lpx_state_info {
   int32_t sweep_rows;           /* rows per workgroup (run length) of the last blocked sweep                       */
   int32_t sweep_kernel;         /* the kernel that swept the bulk of the tableau last (lpx_sweep_kernel_name)      */
   int32_t multi_onehop;         /* lpx_multi: 1 = the last decision launches used the one-hop exchange              */
-  int32_t sweep_clock_mhz;      /* shader clock the chip held over the last k_sweep32_pull / k_sweep64_pull launch (in-kernel
-                                   s_memtime against the 100 MHz counter, probes in the launches around it); 0 = not measured */
+  int32_t sweep_clock_mhz;      /* shader clock the chip held over the last pulled sweep launch (k_sweep32_pull, k_sweep64_one,
+                                   k_sweep64_mfma2, ...: in-kernel s_memtime against the 100 MHz counter, one pair of stamps per XCD
+                                   in the launches around the sweep); 0 = not measured (another sweep kernel ran last) */
   int32_t sweep_cus;            /* CUs the stream of the last blocked sweep could use (all of them outside the overlapped loop) */
   int32_t arith_fused;          /* arithmetic in effect (LPX_OPT_FUSED resolved): 0 = two roundings per update, 1 = fused multiply-add */
 } lpx_state_info;

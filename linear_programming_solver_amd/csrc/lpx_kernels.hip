@@ -1760,12 +1760,20 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   const int64_t ld = P.ld, mp = P.mp;
   const int n = P.n, m = P.m, nb = P.nb, n_old = P.n_old;
   LpxCtl* const ctl = P.ctl;
-  const int G = gridDim.x, T = G * NT, tid = threadIdx.x, gid = blockIdx.x * NT + tid;
+#ifdef LPX_CHAIN2_ONE_XCD   // experiment build: eight times the grid, only the workgroups the dispatcher deals to XCD 0 take part
+  if (blockIdx.x & 7u) return;
+  const unsigned bid = blockIdx.x >> 3;
+  const int G = gridDim.x >> 3;
+#else
+  const unsigned bid = blockIdx.x;   // (workgroup index, as every use below names it)
+  const int G = gridDim.x;
+#endif
+  const int T = G * NT, tid = threadIdx.x, gid = bid * NT + tid;
   const bool lead = gid == 0;                                   // stamps, the next launch's barrier counter
-  const bool book = blockIdx.x == (unsigned)(G - 1) && tid == 0;   // keeps the loop state (off workgroup 0's path)
+  const bool book = bid == (unsigned)(G - 1) && tid == 0;   // keeps the loop state (off workgroup 0's path)
   if (tid == 0) {
     sh_fail = 0;
-    if (P.census) P.census[blockIdx.x] = xcc_id() + 1u;
+    if (P.census) P.census[bid] = xcc_id() + 1u;
   }
   if (lead) st_agent(reinterpret_cast<int32_t*>(P.bar_next), 0);
   int e = ctl->e_next;
@@ -1797,8 +1805,8 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   // Column ownership, fixed for the launch.  With the hand-off, workgroup 0 owns slots 0..255 and nothing else (it is
   // on everybody's critical path); the other workgroups share the rest.  Without it every thread strides over all slots.
   const bool window = !P.dantzig && ld >= 256 && G > 1;
-  const int jfirst = !window ? gid : (blockIdx.x == 0 ? (tid < 256 ? tid : (int)ld) : 256 + (int)(blockIdx.x - 1) * NT + tid);
-  const int jstep = !window ? T : (blockIdx.x == 0 ? (int)ld : T - NT);
+  const int jfirst = !window ? gid : (bid == 0 ? (tid < 256 ? tid : (int)ld) : 256 + (int)(bid - 1) * NT + tid);
+  const int jstep = !window ? T : (bid == 0 ? (int)ld : T - NT);
   const char* const oc_o = reinterpret_cast<const char*>(P.own_col_o);
   const char* const oc_n = reinterpret_cast<const char*>(P.own_col);
   const char* const op_o = reinterpret_cast<const char*>(P.own_prow_o);
@@ -1907,7 +1915,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     // here), at least ra + 1; chunks from there on are straight multiply-adds for the whole wave.
     int reach_a[2];
     {
-      const int row_w = row0 + (int)(blockIdx.x * NT) + (tid & ~63);
+      const int row_w = row0 + (int)(bid * NT) + (tid & ~63);
       unsigned long long h0[2] = {0, 0}, h1[2] = {0, 0};
 #pragma unroll
       for (int h = 0; h < 2 * KB / 64; ++h) {
@@ -2003,7 +2011,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       if (tid < 7) {
         const unsigned d = tid == 0 ? lo32(w.ratio) : tid == 1 ? hi32(w.ratio) : tid == 2 ? lo32(wa) : tid == 3 ? hi32(wa)
                          : tid == 4 ? lo32(wb) : tid == 5 ? hi32(wb) : (unsigned)w.row;
-        __hip_atomic_store(&gran[blockIdx.x * 8 + tid], ((unsigned long long)xtag << 32) | d, __ATOMIC_RELAXED,
+        __hip_atomic_store(&gran[bid * 8 + tid], ((unsigned long long)xtag << 32) | d, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       }
       for (int idx = tid; idx < G * 8; idx += NT) {   // one lane per granule of every workgroup's record
@@ -2280,7 +2288,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
       if (j < (int)ld) load_col(j);
     }
     LPX_C2_STAMP(15)
-    if (window && blockIdx.x == 0) {
+    if (window && bid == 0) {
       // Workgroup 0 has finished slots 0..255.  Under the first-positive rule the next entering slot is the lowest one
       // with c > eps: if there is one among them it is the answer, and the thread that owns it publishes {slot, c[slot],
       // prow_s[slot]} — all the next phase A needs of this decision — as five tagged granules, no drain.  No candidate
@@ -2314,7 +2322,7 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
           }
           for (int d = 0; d < P.n_dev; ++d)
             if (d != P.dev)
-              __hip_atomic_store(&P.arrive_peer[d][blockIdx.x], (unsigned long long)xtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              __hip_atomic_store(&P.arrive_peer[d][bid], (unsigned long long)xtag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
@@ -2365,8 +2373,8 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
     if (e_next < 0) {  // no hand-off (Dantzig, narrow tableau) or no candidate in its window: the full exchange
       const RatioRow w2 = rr_block_min2(cand, sh_rr);
       if (tid == 0) {
-        st_agent(&P.partB[blockIdx.x].ratio, w2.ratio);
-        st_agent(&P.partB[blockIdx.x].row, w2.row);
+        st_agent(&P.partB[bid].ratio, w2.ratio);
+        st_agent(&P.partB[bid].row, w2.row);
       }
       target += (unsigned)G;
       if (!grid_barrier(P.bar, target, &sh_fail, P.fences, P.spin_max)) {
@@ -2817,157 +2825,11 @@ __global__ __launch_bounds__(256, LPX_SWEEP_LB(K)) void k_update_multi(double* _
 #endif
 }
 
-// ---- the steady state of the sweep: a full block of 32 pivots over full 512-column strips --------------------------
-// Same work split and arithmetic as k_update_multi<32>, but the tableau loads are issued by hand so that TWO batches
-// per wave are in flight.  Why: the compiler sinks a software prefetch below the arithmetic that separates it from
-// its first use (and follows a volatile load with s_waitcnt vmcnt(0)), which leaves one batch in flight however many
-// buffers the source names — and the timestamps say a batch's loads come back after ~3 us while its arithmetic takes
-// 1-2 us (profiles/r02_sweep_wg_lifetimes.txt).  asm volatile keeps the loads where they are written; the matching
-// wait names the destination registers as in/out operands so that nothing reads them earlier.  vmcnt counts in issue
-// order: "at most N outstanding" completes every operation that has at least N younger ones, so operations the
-// compiler adds in between (its stores, the odd spill) only lengthen a wait; a wait can only be too short if FEWER
-// operations follow than assumed — hence vmcnt(0) for the last batches of a run, and the first two batches of a run
-// come from ordinary loads the compiler waits for by itself.  Everything that is not a full strip of a full block
-// (np < 32, the partial last strip) is left to k_update_multi<32>(complement = 1), launched right behind.
-__device__ __forceinline__ void strip_load16(d2& x, const char* base, uint32_t off, bool nt) {
-  if (nt) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=&v"(x) : "v"(off), "s"(base) : "memory");
-  else asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(x) : "v"(off), "s"(base) : "memory");
-}
-__device__ __forceinline__ void strip_load8(double& x, const char* base, uint32_t off) {
-  asm volatile("global_load_dwordx2 %0, %1, %2" : "=&v"(x) : "v"(off), "s"(base) : "memory");
-}
-// The wait is TWO statements with a scheduling barrier between them.  A single asm with the registers as in/out
-// operands is not enough: the register allocator may give the asm other registers than the loads' destinations and
-// copy the (not yet arrived) contents over BEFORE the statement — seen in the vmcnt(0) path at the end of a run,
-// where one wave's last batches then came out stale about once in 15 000 runs of a workgroup.  Here the counter is
-// waited for first; nothing crosses the barrier; only then a second, empty asm hands the registers to the compiler
-// (any copy it makes for that statement sits after the barrier, i.e. after the data has arrived).
-// all_follow (uniform): the N younger operations the count assumes have all been issued; otherwise (the last batches
-// of a run) everything is waited for.  One hand-over statement for both cases: no merge of two register assignments.
-template <int N>
-__device__ __forceinline__ void strip_wait4(d2 (&x)[4], bool all_follow) {
-  if (all_follow) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) :: "memory");
-}
-template <int N, int PF>
-__device__ __forceinline__ void strip_wait_parked(double (&x)[PF]) {
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int k = 0; k < PF; ++k) asm volatile("" : "+v"(x[k]) :: "memory");
-}
-
-template <bool NT, bool OOP>
-__global__ __launch_bounds__(256, 2) void k_sweep32_steady(double* __restrict__ A, const double* __restrict__ Asrc,
-                                                           int64_t ld, int m_local,
-                                                           const double* __restrict__ prow_ring,
-                                                           const double* __restrict__ col_ring, int64_t mp,
-                                                           const LpxCtl* __restrict__ ring, int kmax, int rows_per_wg,
-                                                           int nstrips_full) {
-  constexpr int K = 32, RB = 4, NB = 3, CH = 48, PF = K * CH / 256;   // 12 batches per chunk, 6 parked multipliers
-  static_assert((CH / RB) % NB == 0 && 2 * CH <= kSweepMaxRows && K * CH % 256 == 0, "chunk geometry");
-  __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
-  __shared__ int sh_np;
-  // A partly filled block (np < 32: it ended early, or it is the tail of a pivot budget) runs the same straight-line
-  // code: the steps np..31 get the multiplier +0 AND the pivot-row slice +0, and x - (+0 * +0) = x - (+0) = x bit for
-  // bit for every x (-0, infinities and NaNs included) — identities instead of branches.  Below ~16 pivots the time is
-  // the memory's either way.  An empty block is 32 identities: out of place that carries the tableau over.
-  const int np = ring_count(ring, K, kmax, &sh_np);
-  if (np == 0 && !OOP) return;
-  const int strip = blockIdx.x % nstrips_full;
-  const int grp = blockIdx.x / nstrips_full;
-  const int cj = strip * 512 + 2 * threadIdx.x;
-  const int r_begin = grp * rows_per_wg;
-  const int nrows = min(m_local, r_begin + rows_per_wg) - r_begin;   // a multiple of RB (the launcher checks m_local)
-  if (nrows <= 0) return;
-  char* const tile_base = reinterpret_cast<char*>(A + (int64_t)r_begin * ld + strip * 512);
-  const char* const src_base =
-      OOP ? reinterpret_cast<const char*>(Asrc + (int64_t)r_begin * ld + strip * 512) : tile_base;
-  const char* const col_base = reinterpret_cast<const char*>(col_ring + r_begin);
-  const uint32_t row_bytes = (uint32_t)ld * 8u;   // rows_per_wg * ld * 8 < 2^32 (launcher)
-  const uint32_t off0 = threadIdx.x * 16u;
-  const int full = nrows / RB;
-
-  // prologue with ordinary loads: chunk 0's multipliers, the thread's 32 pivot-row slices, batches 0 and 1
-  for (int idx = threadIdx.x; idx < K * CH; idx += 256) {
-    const int sidx = idx / CH, r = idx % CH;
-    sh_col[sidx][r] = (r < nrows && sidx < np) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;
-  }
-  d2 pr[K];
-#pragma unroll
-  for (int s = 0; s < K; ++s) {
-    pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj);
-    if (s >= np) pr[s] = d2{0.0, 0.0};   // uniform
-  }
-  d2 xb[NB][RB];
-#pragma unroll
-  for (int u = 0; u < NB; ++u)
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      xb[u][r] = d2{0.0, 0.0};
-      if (u + 1 < NB && u < full) {  // uniform
-        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(u * RB + r) * row_bytes));
-        xb[u][r] = NT ? __builtin_nontemporal_load(q) : *q;
-      }
-    }
-  __syncthreads();
-
-  const int nchunks = (nrows + CH - 1) / CH;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int half = (ch & 1) * CH;
-    const bool more = ch + 1 < nchunks;   // then this chunk is a full one: 12 batches, 96 memory operations
-    double colpf[PF];
-    if (more) {   // the next chunk's multipliers: requested now (by hand, like the rows), parked, published at the end
-      const int n_next = min(CH, nrows - (ch + 1) * CH);
-#pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int idx = threadIdx.x + k * 256;
-        const int sidx = idx / CH, r = idx % CH;
-        colpf[k] = 0.0;
-        if (r < n_next && sidx < np)
-          strip_load8(colpf[k], col_base, (uint32_t)(((int64_t)sidx * mp + (ch + 1) * CH + r) * 8));
-      }
-    }
-    const int b_lo = ch * (CH / RB), b_hi = min(full, b_lo + CH / RB);
-#pragma unroll 1
-    for (int bt = b_lo; bt < b_hi; bt += NB) {   // b_lo is a multiple of NB: buffer u holds batch bt + u
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        if (bt + u < b_hi) {  // uniform
-          const int r0 = (bt + u) * RB;
-          const bool ahead = bt + u + NB - 1 < full;   // uniform
-          if (ahead) {
-#pragma unroll
-            for (int r = 0; r < RB; ++r)
-              strip_load16(xb[(u + NB - 1) % NB][r], src_base, off0 + (uint32_t)(r0 + (NB - 1) * RB + r) * row_bytes, NT);
-          }
-          if (bt + u >= NB - 1) {
-            // younger than this batch's loads: RB stores and RB loads per batch in between, NB - 1 batches
-            strip_wait4<2 * RB * (NB - 1)>(xb[u], ahead);   // (the tail of the run: fewer operations follow)
-          }
-          sweep_apply<K, RB, kSweepAll>(xb[u], pr, sh_col, K, half + r0 % CH);
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-            d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
-            if (NT) __builtin_nontemporal_store(xb[u][r], q); else *q = xb[u][r];
-          }
-        }
-      }
-    }
-    if (more) {
-      // 96 memory operations were issued after the multiplier requests: they are long back (vmcnt is 6 bits wide)
-      strip_wait_parked<32, PF>(colpf);
-#pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int idx = threadIdx.x + k * 256;
-        sh_col[idx / CH][(CH - half) + idx % CH] = colpf[k];
-      }
-      __syncthreads();
-    }
-  }
-}
+#ifdef LPX_WITH_VARIANTS   // superseded / experiment kernels: csrc/variants/, built by `make variants` only
+#define LPX_VARIANT_PART 1
+#include "variants/lpx_variants.inc"
+#undef LPX_VARIANT_PART
+#endif
 
 // ---- the steady state of the sweep with the tableau staged through LDS by LDS-DMA (round 3) -------------------------
 // Same work split and arithmetic as k_sweep32_steady; what changes is where a batch waits for the fp64 pipe.  There a
@@ -3065,148 +2927,11 @@ __device__ __forceinline__ void sweep_apply_lin(d2 (&x)[RB], const d2 (&pr)[K], 
   }
 }
 
-template <bool NT, bool OOP>
-__global__ __launch_bounds__(256, 2) void k_sweep32_dma(double* __restrict__ A, const double* __restrict__ Asrc,
-                                                        int64_t ld, int m_local,
-                                                        const double* __restrict__ prow_ring,
-                                                        const double* __restrict__ col_ring, int64_t mp,
-                                                        const LpxCtl* __restrict__ ring, int kmax, int cstart,
-                                                        int cstep, int nstrips_full,
-                                                        const double* __restrict__ zeros, int xcd_remap) {
-  // Which rows a workgroup takes.  The tableau's rows go in chunks of CH = 32 (8 batches of RB = 4: the unit the
-  // multipliers are staged in); workgroup (strip, g) takes the chunks g * cstart + c * cstep, c = 0, 1, ...:
-  //   cstep == 1: a contiguous run of cstart chunks (the split of k_sweep32_steady: several rounds of workgroups);
-  //   cstep == G, cstart == 1 (G = workgroups per strip): every G-th chunk.  With the whole grid resident (G x strips =
-  //   two workgroups per CU) all workgroups walk down the tableau together, what the chip has in flight is one window
-  //   of G x 32 whole rows, and the pivot-row slices and the prologue are paid once per sweep instead of once per run.
-  constexpr int K = kDmaK, RB = kDmaRB, NS = kDmaNS, CH = kDmaCH, BPC = CH / RB;
-  // every batch: RB LDS-DMAs + RB stores.  Behind the DMAs of batch bt, when its turn comes: the stores of batch
-  // bt - NS, then DMAs + stores of NS - 1 batches
-  constexpr int kAhead = 2 * RB * NS - RB;
-  static_assert(kAhead <= 60, "vmcnt is six bits wide");
-  __shared__ __attribute__((aligned(16))) char sm[kDmaLdsBytes];   // ONE LDS object (a second one beside LDS-DMA
-                                                                    // staging makes hipcc drain vmcnt before ds_reads)
-  // A partly filled block runs the same straight-line code with identity steps, as in k_sweep32_steady: multiplier +0
-  // (the DMA of a slot >= np reads the zero page) AND pivot-row slice +0, x - (+0 * +0) = x bit for bit.
-  const int np = ring_count(ring, K, kmax, reinterpret_cast<int*>(sm));
-  __syncthreads();   // everyone has read the count before a DMA lands on it
-  if (np == 0 && !OOP) return;
-  // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the XCD's share, MI355X_MICROARCH.md).  With
-  // strip = blockIdx % nstrips an XCD would only ever touch the strips s = x (mod 8), i.e. — the row pitch being a
-  // multiple of the HBM channel interleave — one eighth of the memory channels.  xcd_remap: an XCD takes ALL strips
-  // of every 8th row group instead (and needs only its own groups' multipliers in its L2).
-  int strip, grp;
-  if (xcd_remap) {
-    const int j = blockIdx.x >> 3;
-    strip = j % nstrips_full;
-    grp = (j / nstrips_full) * 8 + (blockIdx.x & 7);
-  } else {
-    strip = blockIdx.x % nstrips_full;
-    grp = blockIdx.x / nstrips_full;
-  }
-  const int cj = strip * 512 + 2 * threadIdx.x;
-  const int nbt = m_local / RB;                       // batches of the whole tableau (m_local % RB == 0: launcher)
-  const int nct = (nbt + BPC - 1) / BPC;              // chunks of the whole tableau (the last one may be partial)
-  const int c0 = grp * cstart;
-  // the workgroup's chunks and batches (only the tableau's last chunk can be short, and only its last owner has it)
-  const int nc = cstep == 1 ? max(0, min(cstart, nct - c0)) : (nct > c0 && grp < cstep ? (nct - c0 + cstep - 1) / cstep : 0);
-  const int last_chunk = c0 + (nc - 1) * cstep;
-  const int nb = nc <= 0 ? 0 : (nc - 1) * BPC + min(BPC, nbt - last_chunk * BPC);
-  if (nb <= 0) return;
-  const int64_t row_bytes = ld * 8;
-  const int64_t batch_bytes = RB * row_bytes;
-  char* const dst_base = reinterpret_cast<char*>(A + strip * 512);
-  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + strip * 512) : dst_base;
-  const uint32_t off0 = threadIdx.x * 16u;
-  const uint32_t rb32 = (uint32_t)row_bytes;          // 3 rows x ld x 8 < 2^32 (launcher)
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t lds_mult = lds_addr_of(sm);
-  char* const stage = sm + kDmaMultBytes + wave * (NS * kDmaSlotBytes);
-  const uint32_t lds_stage = lds_addr_of(stage);
-  const int nchunks = (nb + BPC - 1) / BPC;
-
-  // multipliers of the workgroup's chunk ch -> its half of the image [pivot][row in chunk]; this wave's two pieces (4
-  // pivots x 32 rows each); a lane brings two rows
-  auto mult_dma = [&](int ch) {
-    const int r = (lane & 15) * 2;
-    const int64_t row = ((int64_t)c0 + (int64_t)ch * cstep) * CH + r;
-    const bool in_rows = ch * BPC + (r >> 2) < nb;    // (rows come in fours)
-    const double* src[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int s = (2 * wave + p) * 4 + (lane >> 4);
-      src[p] = (s < np && in_rows) ? col_ring + ((int64_t)s * mp + row) : zeros;
-    }
-    dma_pieces2(src[0], src[1], (uint32_t)__builtin_amdgcn_readfirstlane(
-                                    (int)(lds_mult + (uint32_t)((ch & 1) * (K * CH * 8) + 2 * wave * 1024))));
-  };
-  // first byte of the workgroup's batch bt, relative to the strip's first row
-  auto batch_off = [&](int bt) -> int64_t {
-    return (((int64_t)c0 + (int64_t)(bt / BPC) * cstep) * BPC + bt % BPC) * batch_bytes;
-  };
-  auto batch_dma = [&](int bt) {   // the workgroup's batch bt -> slot bt % NS
-#if LPX_DMA_DIAG == 2
-    if (bt >= NS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
+#ifdef LPX_WITH_VARIANTS
+#define LPX_VARIANT_PART 2
+#include "variants/lpx_variants.inc"
+#undef LPX_VARIANT_PART
 #endif
-    const char* const base = src_base + batch_off(bt);   // uniform
-    dma_batch4<NT>(base, off0, off0 + rb32, off0 + 2 * rb32, off0 + 3 * rb32,
-                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_stage + (uint32_t)((bt % NS) * kDmaSlotBytes))));
-  };
-
-  // prologue: chunk 0's multipliers, the first NS batches, the thread's 32 pivot-row slices; everything is waited for
-  mult_dma(0);
-#pragma unroll
-  for (int u = 0; u < NS; ++u)
-    if (u < nb) batch_dma(u);   // uniform
-  d2 pr[K];
-#pragma unroll
-  for (int s = 0; s < K; ++s) {
-    pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)s * ld + cj);
-    if (s >= np) pr[s] = d2{0.0, 0.0};   // uniform
-  }
-  dma_wait<0>();
-  asm volatile("s_barrier" ::: "memory");
-
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const bool more = ch + 1 < nchunks;   // then this chunk is a full one: BPC batches
-    if (more) mult_dma(ch + 1);           // into the half every wave has left (the barrier at the end of chunk ch - 1)
-    const double* const mhalf = reinterpret_cast<const double*>(sm) + (ch & 1) * (K * CH);
-    const int b_lo = ch * BPC, b_hi = min(nb, b_lo + BPC);
-#pragma unroll 1
-    for (int bt = b_lo; bt < b_hi; ++bt) {
-      // this batch's DMAs have landed once at most kAhead younger operations are outstanding; at the end of the run
-      // fewer follow: RB per batch that is still to come (their stores), plus the RB * NS stores in between
-      const int rem = nb - 1 - bt;
-      if (rem >= NS - 1) dma_wait<kAhead>();
-      else if (rem == 2) dma_wait<(NS >= 3 ? RB * NS + 2 * RB : 0)>();
-      else if (rem == 1) dma_wait<(NS >= 2 ? RB * NS + RB : 0)>();
-      else dma_wait<RB * NS>();
-      const char* const slot = stage + (bt % NS) * kDmaSlotBytes + lane * 16;
-      d2 x[RB];
-#pragma unroll
-      for (int r = 0; r < RB; ++r) x[r] = *reinterpret_cast<const d2*>(slot + r * 1024);
-      if (bt + NS < nb) batch_dma(bt + NS);   // refill the slot just read (the statement waits for the reads first)
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if LPX_DMA_DIAG != 1   // (diagnostic build 1: the memory pass alone — every batch through LDS, no arithmetic)
-      sweep_apply_lin<K, RB, CH>(x, pr, mhalf + (bt - b_lo) * RB);
-#endif
-      char* const out = dst_base + batch_off(bt);   // uniform
-#if LPX_DMA_DIAG == 2   // (diagnostic build 2: the arithmetic alone — one batch read, nothing stored)
-      if (x[0].x == 1.2345e300)
-#endif
-#pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        d2* q = reinterpret_cast<d2*>(out + (off0 + (uint32_t)r * rb32));
-        if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
-      }
-    }
-    if (more) {
-      dma_wait<RB * BPC - RB>();   // the next chunk's pieces were issued before this chunk's BPC x RB stores
-      asm volatile("s_barrier" ::: "memory");
-    }
-  }
-}
 
 // ---- the steady state of the sweep, every wave on its own, batches PULLED in address order (round 3) ----------------
 // What bounds k_sweep32_dma is its memory pass: on the same GPU a one-shot copy of the tableau in 4-row x 512-column
@@ -3267,7 +2992,7 @@ __global__ __launch_bounds__(256) void k_pack_multipliers(const double* __restri
   const int np = ring_count(ring, KP, kmax, &sh_np);
   // clock probe (lpx_state_info.sweep_clock_mhz): shader-clock and 100 MHz stamps in front of the sweep; k_block_fixup
   // takes the matching pair behind it
-  if (clk && blockIdx.x < 64 && threadIdx.x == 0) {   // (s_memtime is a per-XCD counter: a pair of stamps per XCD)
+  if (clk && blockIdx.x < 8 && threadIdx.x == 0) {   // (s_memtime is a per-XCD counter: a pair of stamps per XCD, by ONE workgroup of each — workgroup i runs on XCD i % 8)
     const unsigned x = xcc_id() & 7u;
     clk[x * 4 + 0] = __builtin_amdgcn_s_memtime(); clk[x * 4 + 1] = wall_clock64();
   }
@@ -3421,214 +3146,11 @@ __global__ __launch_bounds__(256, 2) void k_sweep32_pull(double* __restrict__ A,
   dma_wait<0>();   // the pending ticket atomics write registers of this wave: let them land before it ends
 }
 
-// ---- blocks of 33..64 pivots: k_sweep32_pull's worker split into a PAIR of waves (round 3) ---------------------------
-// 64 pivot-row slices do not fit one wave's registers, so a sub-strip's worker is two waves of one workgroup: stage 1
-// is k_sweep32_pull's loop over pivots 0..31 (tickets, LDS-DMA, hand-counted vmcnt) except that a finished batch goes
-// into a hand-over slot in LDS instead of to memory; stage 2 takes it from there (lane t reads what lane t wrote),
-// applies pivots 32..63 with multipliers it has brought itself (the ticket of batch i+2 is in an LDS ring long before:
-// stage 1 knows its tickets three batches ahead) and stores the rows.  The two waves meet only through LDS words —
-// `seq` (batches handed over), `used` (batches taken), `done` — polled with s_sleep; an LDS queue is in-order per wave,
-// so data written before a word is visible to whoever has seen the word.  Same arithmetic per entry as two passes of
-// 32; half the HBM bytes per pivot.  A block of fewer than 33 pivots is left to the generic two-pass path.
-constexpr int kPairHS = 3;                                              // hand-over slots
-constexpr int kPairBytes = kPullWaveBytes + kPairHS * kDmaSlotBytes + kPullNM * 1024 + 256;   // per pair: 32.25 KiB
-static_assert(4 * kPairBytes <= 160 * 1024, "two workgroups (four pairs) per CU");
-
-__device__ __forceinline__ void lds_word_store(int* p, int v) {
-  asm volatile("" ::: "memory");
-  *reinterpret_cast<volatile int*>(p) = v;
-  asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ int lds_word_load(const int* p) {   // every lane reads the word; the result is made uniform
-  asm volatile("" ::: "memory");
-  const int v = *reinterpret_cast<const volatile int*>(p);
-  asm volatile("" ::: "memory");
-  return __builtin_amdgcn_readfirstlane(v);
-}
-
-template <bool NT, bool OOP>
-__global__ __launch_bounds__(256, 2) void k_sweep64_pull(double* __restrict__ A, const double* __restrict__ Asrc,
-                                                         int64_t ld, int m_local,
-                                                         const double* __restrict__ prow_ring,
-                                                         const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
-                                                         const double* __restrict__ col_packed,   // [batch][64][4]
-                                                         unsigned* __restrict__ tickets,
-                                                         unsigned* __restrict__ fail_word) {
-  constexpr int K = 32, RB = kDmaRB, NS = kPullNS, NM = kPullNM, HS = kPairHS, TR = 8;
-  constexpr int kOps1 = RB + 2;                      // stage 1 per iteration: RB row DMAs, 1 multiplier DMA, 1 atomic
-  constexpr int kAhead1 = (NS - 1) * kOps1;          // younger than the atomic of iteration i - NS at iteration i's wait
-  constexpr int kOps2 = RB + 1;                      // stage 2 per iteration: 1 multiplier DMA, RB stores
-  constexpr int kAhead2 = RB + (NS - 1) * kOps2;     // younger than the multiplier DMA of batch i (issued at i - NS)
-  __shared__ __attribute__((aligned(16))) char sm[2 * kPairBytes];
-  const int np = ring_count(ring, 2 * K, kmax, reinterpret_cast<int*>(sm));
-  __syncthreads();   // everyone has read the count before anything lands on it
-  if (np <= K) return;   // 0..32 pivots: the generic kernels behind this launch take the block (two passes)
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int pair = wave & 1, stage = wave >> 1;
-  // the grid is G workgroups per PAIR of sub-strips; XCD x walks the pairs shifted by x * npairs / 8 (see k_sweep32_pull)
-  const int npairs = nstrips_full * 2;
-  const int pp = (npairs % 8 == 0)
-                     ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(npairs / 8)) % (unsigned)npairs)
-                     : (int)(blockIdx.x % (unsigned)npairs);
-  const int sub = pp * 2 + pair;
-  const int nbt = m_local / RB;
-  unsigned* const ctr = tickets + sub * 32;
-  const int64_t row_bytes = ld * 8;
-  const int64_t batch_bytes = RB * row_bytes;
-  char* const dst_base = reinterpret_cast<char*>(A + sub * 128);
-  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + sub * 128) : dst_base;
-  const uint32_t off0 = lane * 16u;
-  const uint32_t rb32 = (uint32_t)row_bytes;
-  // LDS of the pair: stage 1's batch slots and multiplier slots, the hand-over slots, stage 2's multiplier slots, words
-  char* const base = sm + pair * kPairBytes;
-  char* const stage1 = base;
-  char* const mult1 = stage1 + NS * kDmaSlotBytes;
-  char* const hand = base + kPullWaveBytes;
-  char* const mult2 = hand + HS * kDmaSlotBytes;
-  int* const words = reinterpret_cast<int*>(mult2 + NM * 1024);   // [0] seq, [1] used, [2] done, [8 ..] ticket ring
-  int* const tring = words + 8;
-  if (threadIdx.x < 128) {   // both pairs' words: nothing handed over, nothing taken, not done
-    int* const w = reinterpret_cast<int*>(sm + (threadIdx.x >> 6) * kPairBytes + kPullWaveBytes + HS * kDmaSlotBytes + NM * 1024);
-    if (lane < 8 + TR) w[lane] = lane >= 8 ? INT_MAX : 0;
-  }
-  __syncthreads();
-  // the wave's 32 pivot-row slices: pivots 0..31 (stage 1) or 32..63 (stage 2; +0 for the identity steps beyond np)
-  d2 pr[K];
-  {
-    const double* const pbase = prow_ring + ((int64_t)(stage * K) * ld + sub * 128 + 2 * lane);
-    const int npl = np - stage * K;   // valid pivots of this stage
-#pragma unroll
-    for (int s = 0; s < K; ++s) {
-      pr[s] = *reinterpret_cast<const d2*>(pbase + (int64_t)s * ld);
-      if (s >= npl) pr[s] = d2{0.0, 0.0};   // uniform
-    }
-  }
-
-  // ONE loop for both stages (one instance of the 32-step arithmetic: two copies made the register allocator spill the
-  // slices); what differs per stage sits in small wave-uniform branches:
-  //                    stage 1 (pivots 0..31)                         stage 2 (pivots 32..63)
-  //   ticket of i+3    its own atomic, published in the LDS ring      read from the LDS ring
-  //   batch i from     its LDS-DMA slot (rows of the tableau)         the hand-over slot, once seq > i
-  //   LDS-DMA issued   rows + multipliers of batch i+3, the atomic    multipliers of batch i+3
-  //   batch i goes     into the hand-over slot (once used > i - HS)   to memory (nt stores)
-  const bool s1 = stage == 0;
-  const uint32_t lds_rows = lds_addr_of(stage1), lds_mult = lds_addr_of(s1 ? mult1 : mult2);
-  const char* const in_slots = s1 ? stage1 : hand;
-  const char* const mult_slots = s1 ? mult1 : mult2;
-  auto issue = [&](int t, int it) {   // batch t becomes iteration it's
-    const uint32_t lm = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_mult + (uint32_t)((it % NM) * 1024)));
-    const char* const mbase = reinterpret_cast<const char*>(col_packed) + (int64_t)t * 2048 + (s1 ? 0 : 1024);
-    if (s1) {
-      dma_batch4m<NT>(src_base + (int64_t)t * batch_bytes, off0, off0 + rb32, off0 + 2 * rb32, off0 + 3 * rb32,
-                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds_rows + (uint32_t)((it % NS) * kDmaSlotBytes))),
-                      mbase, lm);
-    } else {
-      unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(off0), "s"(mbase), "s"(lm) : "memory");
-    }
-  };
-  static_assert(HS == NS, "one unrolled loop: batch slot and hand-over slot of iteration i are both i % NS");
-  unsigned tk[NS];   // (stage 1 only)
-  int bq[NS + 1];   // bq[k]: the batch of iteration i + k (>= nbt: none)
-  if (s1) {
-#pragma unroll
-    for (int u = 0; u < NS; ++u) ticket_pull(tk[u], ctr);
-    dma_wait<0>();
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      bq[u] = ticket_take(tk[u]);
-      if (lane == 0) lds_word_store(&tring[u], bq[u]);
-      if (bq[u] < nbt) issue(bq[u], u);
-    }
-#pragma unroll
-    for (int u = 0; u < NS; ++u) ticket_pull(tk[u], ctr);
-    dma_wait<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tickets 0..NS-1 are in the ring: stage 2 may start
-  } else {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      bq[u] = lds_word_load(&tring[u]);
-      if (bq[u] < nbt) issue(bq[u], u);
-    }
-    dma_wait<0>();
-  }
-  int full = 0;   // consecutive most recent iterations that issued all their operations
-#pragma unroll 1
-  for (int i0 = 0;; i0 += NS) {
-    if (bq[0] >= nbt) break;   // tickets only grow: nothing is left for this pair
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      const int i = i0 + u;
-      const int t = bq[0];
-      if (t < nbt) {   // uniform
-        if (s1) {
-          if (full >= NS) dma_wait<kAhead1>(); else if (i >= NS) dma_wait<0>();
-          bq[NS] = ticket_take(tk[u]);
-          if (lane == 0) lds_word_store(&tring[(i + NS) % TR], bq[NS]);   // (its previous tenant was read long ago)
-        } else {
-          unsigned spins = 0;
-          while (lds_word_load(&words[0]) < i + 1) {   // batch i handed over?
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 26)) {   // never in a healthy run: keeps a bug from hanging the device, and says so
-              if (lane == 0) atomicOr(fail_word, 1u);   // (the host turns it into LPX_DEVICE_ERROR at the end of the loop)
-              break;
-            }
-          }
-          if (full >= NS) dma_wait<kAhead2>(); else if (i >= NS) dma_wait<0>();
-          bq[NS] = lds_word_load(&tring[(i + NS) % TR]);   // published by stage 1 in ITS iteration i: it is past that
-        }
-        const char* const slot = in_slots + u * kDmaSlotBytes + lane * 16;
-        d2 x[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) x[r] = *reinterpret_cast<const d2*>(slot + r * 1024);
-        const bool more = bq[NS] < nbt;
-        if (s1) {
-          if (more) issue(bq[NS], i + NS);   // refills the slot just read (the statement waits for the reads first)
-          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          ticket_pull(tk[u], ctr);
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (lane == 0) lds_word_store(&words[1], i + 1);   // the hand-over slot may be refilled
-          if (more) issue(bq[NS], i + NS);
-        }
-        full = more ? full + 1 : 0;
-        sweep_apply_lin<K, RB, RB>(x, pr, reinterpret_cast<const double*>(mult_slots + (i % NM) * 1024));
-        if (s1) {
-          if (i >= HS) {   // slot i % HS is free once stage 2 has taken batch i - HS
-            unsigned spins = 0;
-            while (lds_word_load(&words[1]) < i - HS + 1) {
-              __builtin_amdgcn_s_sleep(1);
-              if (++spins > (1u << 26)) {
-                if (lane == 0) atomicOr(fail_word, 2u);
-                break;
-              }
-            }
-          }
-          char* const hs = hand + u * kDmaSlotBytes + lane * 16;
-#pragma unroll
-          for (int r = 0; r < RB; ++r) *reinterpret_cast<d2*>(hs + r * 1024) = x[r];
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          if (lane == 0) lds_word_store(&words[0], i + 1);
-        } else {
-          char* const out = dst_base + (int64_t)t * batch_bytes;   // uniform
-#pragma unroll
-          for (int r = 0; r < RB; ++r) {
-            d2* q = reinterpret_cast<d2*>(out + (off0 + (uint32_t)r * rb32));
-            if (NT) __builtin_nontemporal_store(x[r], q); else *q = x[r];
-          }
-        }
-      } else {
-        bq[NS] = INT_MAX;
-      }
-#pragma unroll
-      for (int k = 0; k < NS; ++k) bq[k] = bq[k + 1];
-    }
-  }
-  dma_wait<0>();   // stage 1's pending ticket atomics write registers of this wave: let them land before it ends
-}
+#ifdef LPX_WITH_VARIANTS   // superseded / experiment kernels: csrc/variants/, built by `make variants` only
+#define LPX_VARIANT_PART 3
+#include "variants/lpx_variants.inc"
+#undef LPX_VARIANT_PART
+#endif
 
 // ---- blocks of 33..64 pivots by ONE wave per sub-strip (round 4) -----------------------------------------------------
 // k_sweep64_pull needs a PAIR of waves per 128-column sub-strip because 64 pivot-row slices of two doubles do not fit one
@@ -3832,7 +3354,7 @@ __global__ __launch_bounds__(256) void k_pack_multipliers_mfma(const double* __r
                                                                int nsub, long long* __restrict__ clk, int pairs) {
   __shared__ int sh_np;
   const int np = ring_count(ring, 64, kmax, &sh_np);
-  if (clk && blockIdx.x < 64 && threadIdx.x == 0) {   // (s_memtime is a per-XCD counter: a pair of stamps per XCD)
+  if (clk && blockIdx.x < 8 && threadIdx.x == 0) {   // (s_memtime is a per-XCD counter: a pair of stamps per XCD, by ONE workgroup of each — workgroup i runs on XCD i % 8)
     const unsigned x = xcc_id() & 7u;
     clk[x * 4 + 0] = __builtin_amdgcn_s_memtime(); clk[x * 4 + 1] = wall_clock64();
   }
@@ -3851,109 +3373,12 @@ __global__ __launch_bounds__(256) void k_pack_multipliers_mfma(const double* __r
   }
 }
 
-template <bool NT, bool OOP>
-__global__ __launch_bounds__(256, 1) void k_sweep64_mfma(double* __restrict__ A, const double* __restrict__ Asrc,
-                                                         int64_t ld, int m_local,
-                                                         const double* __restrict__ prow_ring,
-                                                         const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
-                                                         const double* __restrict__ colM,   // [tile][group][lane]
-                                                         unsigned* __restrict__ tickets) {
-  constexpr int NG = 16, CT = 4;   // pivot groups of four, column tiles of sixteen
-  __shared__ int sh_np;
-  const int np = ring_count(ring, 64, kmax, &sh_np);
-  if (np <= 32) return;   // 0..32 pivots: the generic kernels behind this launch take the block (two passes)
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int ngroups = nstrips_full * 2;
-  const int grp = (ngroups % 8 == 0)
-                      ? (int)(((blockIdx.x >> 3) + (blockIdx.x & 7) * (unsigned)(ngroups / 8)) % (unsigned)ngroups)
-                      : (int)(blockIdx.x % (unsigned)ngroups);
-  const int sub = grp * 4 + wave;                  // 64-column sub-strip
-  const int ntiles = m_local / 16;                 // (m_local % 16 == 0: launcher)
-  unsigned* const ctr = tickets + sub * 32;
-  const int64_t row_bytes = ld * 8;
-  char* const dst_base = reinterpret_cast<char*>(A + sub * 64);
-  const char* const src_base = OOP ? reinterpret_cast<const char*>(Asrc + sub * 64) : dst_base;
-  const uint32_t rb32 = (uint32_t)row_bytes;       // 16 rows x ld x 8 < 2^32 (launcher)
-  const uint32_t off_c = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 8u;   // row lane / 16, column lane % 16
-  // B operands: pivot 4 g + lane / 16, column 16 ct + lane % 16 of the sub-strip; +0 for the identity steps
-  double bq[NG][CT];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int s = 4 * g + (lane >> 4);
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-      bq[g][ct] = s < np ? prow_ring[(int64_t)s * ld + sub * 64 + ct * 16 + (lane & 15)] : 0.0;
-  }
-  // a ticket: the atomic is ISSUED in front of a tile's loads and its value TAKEN behind the arithmetic that follows
-  // (vmcnt counts in order: waiting for the ticket then waits for nothing younger than what the next tile needs anyway)
-  auto pull = [&]() -> unsigned {
-    unsigned t = 0;
-    if (lane == 0) t = atomicAdd(ctr, 1u);
-    return t;
-  };
-  auto take = [&](unsigned raw) -> int { return __builtin_amdgcn_readfirstlane((int)raw); };
-  auto load_tile = [&](int t, d4v (&c)[CT], double (&a)[NG]) {
-    const char* const base = src_base + (int64_t)t * 16 * row_bytes;   // uniform
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const double* q = reinterpret_cast<const double*>(base + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
-        c[ct][r] = NT ? __builtin_nontemporal_load(q) : *q;
-      }
-    const double* const am = colM + (int64_t)t * 1024 + lane;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) a[g] = am[g * 64];
-  };
-  auto work_tile = [&](int t, d4v (&c)[CT], const double (&a)[NG]) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bq[g][ct], c[ct], 0, 0, 0);
-    char* const out = dst_base + (int64_t)t * 16 * row_bytes;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        double* q = reinterpret_cast<double*>(out + (off_c + (uint32_t)(4 * r) * rb32 + (uint32_t)ct * 128u));
-        if (NT) __builtin_nontemporal_store(c[ct][r], q); else *q = c[ct][r];
-      }
-  };
-  d4v c0[CT], c1[CT], c2[CT];
-  double a0[NG], a1[NG], a2[NG];
-  int t0, t1, t2;
-  {
-    const unsigned r0 = pull(), r1 = pull(), r2 = pull();
-    t0 = take(r0); t1 = take(r1); t2 = take(r2);
-  }
-  if (t0 < ntiles) load_tile(t0, c0, a0);
-  if (t1 < ntiles) load_tile(t1, c1, a1);
-#pragma unroll 1
-  while (t0 < ntiles) {   // tickets only grow: t0 >= ntiles means nothing is left for this wave
-    const unsigned r3 = pull();
-    if (t2 < ntiles) load_tile(t2, c2, a2);
-    __builtin_amdgcn_sched_barrier(0);
-    work_tile(t0, c0, a0);
-    __builtin_amdgcn_sched_barrier(0);
-    const int t3 = take(r3);
-    if (t1 >= ntiles) break;
-    const unsigned r4 = pull();
-    if (t3 < ntiles) load_tile(t3, c0, a0);
-    __builtin_amdgcn_sched_barrier(0);
-    work_tile(t1, c1, a1);
-    __builtin_amdgcn_sched_barrier(0);
-    const int t4 = take(r4);
-    if (t2 >= ntiles) break;
-    const unsigned r5 = pull();
-    if (t4 < ntiles) load_tile(t4, c1, a1);
-    __builtin_amdgcn_sched_barrier(0);
-    work_tile(t2, c2, a2);
-    __builtin_amdgcn_sched_barrier(0);
-    const int t5 = take(r5);
-    t0 = t3; t1 = t4; t2 = t5;
-  }
-}
+#ifdef LPX_WITH_VARIANTS
+#define LPX_VARIANT_PART 4
+#include "variants/lpx_variants.inc"
+#undef LPX_VARIANT_PART
+#endif
+
 
 // Second form: TWO waves per SIMD.  k_sweep64_mfma keeps the B operands in 128 VGPRs and therefore runs one wave per
 // SIMD: while that wave issues a tile's 48 loads and 16 stores and waits for the last MFMAs of a tile, the matrix pipe
@@ -3971,23 +3396,17 @@ __global__ __launch_bounds__(256, 1) void k_sweep64_mfma(double* __restrict__ A,
 //  * the loop body is straight-line: the tile of a ticket past the end is CLAMPED to the last tile for its loads (a
 //    re-read, two per wave) and the loop is left before its arithmetic, so no conditional load makes the compiler's
 //    vmcnt bookkeeping fall back to draining counts.
-#ifndef LPX_MFMA_DIAG
-#define LPX_MFMA_DIAG 0   // timing experiments only (results wrong): 2 no stores, 4 no tile loads, 8 no MFMAs, 16 no A loads
-#endif
 constexpr int kMfma2LdsBytes = 2 * 16 * 4 * 64 * 8;
 static_assert(2 * kMfma2LdsBytes <= 160 * 1024, "two workgroups per CU");
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
-#ifndef LPX_MFMA_SHAPE
-#define LPX_MFMA_SHAPE 0   // copy-shape experiments of the diagnostic builds (1: 4 rows x 256 B per instruction, 2: 2 x 512 B, 3: 1 x 512 B)
-#endif
 template <bool NT, bool OOP>
 __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const double* Asrc,   // (no __restrict__: see below)
                                                           int64_t ld, int m_local,
                                                           const double* __restrict__ prow_ring,
                                                           const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
                                                           const double* colM,   // [tile][group][lane]
-                                                          unsigned* tickets, int a_mask) {
+                                                          unsigned* tickets) {
   constexpr int NG = 16, CT = 4;
   constexpr int kRsrcWord3 = 0x00020000;           // raw buffer, 32-bit data format (gfx9 family)
   constexpr int kAuxNt = NT ? 2 : 0;               // cache policy bit 1 = nt
@@ -4023,111 +3442,57 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
     const int tt = max(0, min(t, ntiles - 1));                          // uniform; past the end: the last tile again
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(src_base) + (int64_t)(tt >> 1) * 16 * row_bytes + (tt & 1) * 512, 0, -1, kRsrcWord3);
-#if LPX_MFMA_SHAPE == 0
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        if (LPX_MFMA_DIAG & 4) c[ct][r] = (double)(lane + r + ct + t);
-        else c[ct][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, off_c + (uint32_t)ct * 128u,
-                                                                                         (int)((uint32_t)(4 * r) * rb32), kAuxNt));
-      }
-#else   // copy-shape experiments (with LPX_MFMA_DIAG = 24 only: the register layout is not the MFMA's)
-#pragma unroll
-    for (int i = 0; i < (LPX_MFMA_SHAPE == 3 ? 16 : 8); ++i) {
-      if (LPX_MFMA_SHAPE == 1) {        // 4 rows x 256 B per instruction
-        const uint32_t vo = (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 16u + (uint32_t)(i & 1) * 256u;
-        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rc, vo, (int)((uint32_t)(4 * (i >> 1)) * rb32), kAuxNt);
-        c[2 * (i & 1)][i >> 1] = __builtin_bit_cast(double, v2u{x[0], x[1]});
-        c[2 * (i & 1) + 1][i >> 1] = __builtin_bit_cast(double, v2u{x[2], x[3]});
-      } else if (LPX_MFMA_SHAPE == 2) { // 2 rows x 512 B per instruction
-        const uint32_t vo = (uint32_t)(lane >> 5) * rb32 + (uint32_t)(lane & 31) * 16u;
-        const v4u x = __builtin_amdgcn_raw_buffer_load_b128(rc, vo, (int)((uint32_t)(2 * i) * rb32), kAuxNt);
-        c[2 * (i & 1)][i >> 1] = __builtin_bit_cast(double, v2u{x[0], x[1]});
-        c[2 * (i & 1) + 1][i >> 1] = __builtin_bit_cast(double, v2u{x[2], x[3]});
-      } else {                          // 1 row x 512 B per instruction (dwordx2)
-        c[i & 3][i >> 2] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, off_a, (int)((uint32_t)i * rb32), kAuxNt));
-      }
-    }
-#endif
+      for (int ct = 0; ct < CT; ++ct)
+        c[ct][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rc, off_c + (uint32_t)ct * 128u,
+                                                                                    (int)((uint32_t)(4 * r) * rb32), kAuxNt));
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double*>(colM) + (int64_t)((tt >> 1) & a_mask) * 1024, 0, -1, kRsrcWord3);   // (a_mask = -1; 0: timing experiment only)
+        const_cast<double*>(colM) + (int64_t)(tt >> 1) * 1024, 0, -1, kRsrcWord3);
 #pragma unroll
     for (int p = 0; p < NG / 2; ++p) {   // (k_pack_multipliers_mfma, pairs: the A operands of groups 2 p and 2 p + 1 side by side)
-      if (LPX_MFMA_DIAG & 16) { a[2 * p] = (double)(lane + p + t); a[2 * p + 1] = (double)(lane - p + t); continue; }
       const v4u x = __builtin_amdgcn_raw_buffer_load_b128(ra, 2u * off_a + (uint32_t)(p & 3) * 1024u, (p >> 2) * 4096, 0);
       a[2 * p] = __builtin_bit_cast(double, v2u{x[0], x[1]});
       a[2 * p + 1] = __builtin_bit_cast(double, v2u{x[2], x[3]});
     }
   };
-#ifndef LPX_MFMA_BPIPE
-#define LPX_MFMA_BPIPE 1
-#endif
-#ifndef LPX_MFMA_SB
-#define LPX_MFMA_SB 1   // 1: scheduling barriers between a tile's loads and the previous tile's arithmetic (diagnostic builds: 0)
-#endif
-#if LPX_MFMA_SB
+// scheduling barrier between a tile's loads and the previous tile's arithmetic (without it the compiler sinks the loads
+// behind the MFMA chain: three times slower, profiles/r04_sweep64_mfma2_no_sched_barriers.txt)
 #define LPX_MFMA_FENCE __builtin_amdgcn_sched_barrier(0)
-#else
-#define LPX_MFMA_FENCE (void)0
-#endif
   auto work_tile = [&](int t, d4v (&c)[CT], const double (&a)[NG]) {
     const double* const bl = sh_b + (max(0, min(t, ntiles - 1)) & 1) * (NG * CT * 64) + lane;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        if (LPX_MFMA_DIAG & 8) { if (g == 0) c[ct][0] += a[ct] + a[ct + 4] + a[ct + 8] + a[ct + 12]; }
-        else c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bl[(g * CT + ct) * 64], c[ct], 0, 0, 0);
+        c[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], bl[(g * CT + ct) * 64], c[ct], 0, 0, 0);
       }
-#if LPX_MFMA_BPIPE   // the B operands of group g + 1 (two ds_read2st64_b64) are asked for in front of group g's four MFMAs
+    // the B operands of group g + 1 (two ds_read2st64_b64) are asked for in front of group g's four MFMAs
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     }
-#endif
     // a ticket past the end: the arithmetic runs on the re-read last tile and the stores are DROPPED by the buffer's range
     // check (num_records 0), so the loop body has no exit but its back edge
     const int tt = max(0, min(t, ntiles - 1));
     char* const out = dst_base + (int64_t)(tt >> 1) * 16 * row_bytes + (tt & 1) * 512;
     const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(out, 0, __builtin_amdgcn_readfirstlane((unsigned)t < (unsigned)ntiles ? -1 : 0), kRsrcWord3);
-    if (LPX_MFMA_DIAG & 2) {   // one store per tile keeps the arithmetic alive
-      if (lane == 0) *reinterpret_cast<double*>(out) = c[0][0] + c[1][1] + c[2][2] + c[3][3] + c[0][3] + c[1][2] + c[2][1] + c[3][0] + c[0][1] + c[1][0] + c[2][3] + c[3][2] + c[0][2] + c[1][3] + c[2][0] + c[3][1];
-      return;
-    }
-#if LPX_MFMA_SHAPE == 0
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (double)c[ct][r]), rd, off_c + (uint32_t)ct * 128u,
                                               (int)((uint32_t)(4 * r) * rb32), kAuxNt);
-#else
-#pragma unroll
-    for (int i = 0; i < (LPX_MFMA_SHAPE == 3 ? 16 : 8); ++i) {
-      if (LPX_MFMA_SHAPE == 3) {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, (double)c[i & 3][i >> 2]), rd, off_a, (int)((uint32_t)i * rb32), kAuxNt);
-      } else {
-        const v2u lo = __builtin_bit_cast(v2u, (double)c[2 * (i & 1)][i >> 1]), hi = __builtin_bit_cast(v2u, (double)c[2 * (i & 1) + 1][i >> 1]);
-        const v4u x = {lo[0], lo[1], hi[0], hi[1]};
-        if (LPX_MFMA_SHAPE == 1)
-          __builtin_amdgcn_raw_buffer_store_b128(x, rd, (uint32_t)(lane >> 4) * rb32 + (uint32_t)(lane & 15) * 16u + (uint32_t)(i & 1) * 256u,
-                                                 (int)((uint32_t)(4 * (i >> 1)) * rb32), kAuxNt);
-        else
-          __builtin_amdgcn_raw_buffer_store_b128(x, rd, (uint32_t)(lane >> 5) * rb32 + (uint32_t)(lane & 31) * 16u, (int)((uint32_t)(2 * i) * rb32), kAuxNt);
-      }
-    }
-#endif
   };
   // A ticket is pulled a whole step before it is taken: pulled in front of step i - 1's loads, taken in front of step i's.
   // vmcnt counts in order, so the wait in front of the take covers exactly what is OLDER than step i - 1's loads, stores and
   // step i's pull (41 operations) — operations that have had a step's arithmetic to complete and that step i's MFMAs need
   // anyway.  (Taken behind the same step's stores, first version, every step ended by waiting for the loads and stores it
   // had just issued.)
-  constexpr int kTileOps = LPX_MFMA_SHAPE == 0 || LPX_MFMA_SHAPE == 3 ? 16 : 8;
-  constexpr int kStepOps = ((LPX_MFMA_DIAG & 4) ? 0 : kTileOps) + ((LPX_MFMA_DIAG & 16) ? 0 : 8) + ((LPX_MFMA_DIAG & 2) ? 0 : kTileOps);
+  constexpr int kStepOps = 16 + 8 + 16;   // a step's tile loads, A-operand loads and stores
   static_assert(kStepOps + 1 <= 63, "vmcnt is six bits wide");
   auto take = [&](unsigned& tk) -> int {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kStepOps + 1) : "memory");
@@ -4178,146 +3543,18 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
 }
 
 #undef LPX_MFMA_FENCE
+#ifdef LPX_WITH_VARIANTS
+#define LPX_VARIANT_PART 7
+#include "variants/lpx_variants.inc"
+#undef LPX_VARIANT_PART
+#endif
 #endif  // LPX_FUSED
 
-// ---- 64 pivots per pass: two stages of 32 inside one workgroup ------------------------------------------------------
-// At K = 32 the sweep is bound by memory (16 m n bytes per pass at ~5 TB/s), not by the 2 m n K unfused fp64
-// operations; twice the pivots per pass halves the bytes per pivot.  A thread cannot hold 64 pivot-row slices (256
-// registers), so the workgroup is a two-stage pipeline over the same 512-column strip: waves 0-3 hold the slices of
-// pivots 0..31, load a batch of RB rows from the tableau (by hand, two batches ahead, as k_sweep32_steady), apply their
-// 32 steps and hand the batch over in LDS; waves 4-7 hold the slices of pivots 32..63, take the batch handed over in
-// the previous round, apply their 32 steps and store it.  Lane t of wave w + 4 reads exactly what lane t of wave w
-// wrote; one workgroup barrier per round separates the two hand-over slots.  The arithmetic per entry is the same
-// 64 sequential steps in the same order as two passes of 32.
-template <bool NT, bool OOP>
-__global__ __launch_bounds__(512) void k_sweep64_pipe(double* __restrict__ A, const double* __restrict__ Asrc,
-                                                      int64_t ld, int m_local,
-                                                      const double* __restrict__ prow_ring,
-                                                      const double* __restrict__ col_ring, int64_t mp,
-                                                      const LpxCtl* __restrict__ ring, int kmax, int rows_per_wg,
-                                                      int nstrips_full) {
-  constexpr int K = 64, KS = 32, RB = 4, NB = 3, CH = 48, PF = K * CH / 512;   // 12 rounds per chunk, 6 parked multipliers
-  static_assert((CH / RB) % NB == 0 && 2 * CH <= kSweepMaxRows && K * CH % 512 == 0 && PF == 6, "chunk geometry");
-  __shared__ __attribute__((aligned(16))) double sh_col[K][kSweepMaxRows];
-  __shared__ __attribute__((aligned(16))) d2 sh_x[2][RB][256];
-  __shared__ int sh_np;
-  if (ring_count(ring, K, kmax, &sh_np) != K) return;   // a partly filled block: the generic kernels take all of it
-  const int stage = threadIdx.x >> 8, t = threadIdx.x & 255;   // wave-uniform stage
-  const int strip = blockIdx.x % nstrips_full;
-  const int grp = blockIdx.x / nstrips_full;
-  const int cj = strip * 512 + 2 * t;
-  const int r_begin = grp * rows_per_wg;
-  const int nrows = min(m_local, r_begin + rows_per_wg) - r_begin;   // a multiple of RB (the launcher checks m_local)
-  if (nrows <= 0) return;
-  char* const tile_base = reinterpret_cast<char*>(A + (int64_t)r_begin * ld + strip * 512);
-  const char* const src_base =
-      OOP ? reinterpret_cast<const char*>(Asrc + (int64_t)r_begin * ld + strip * 512) : tile_base;
-  const char* const col_base = reinterpret_cast<const char*>(col_ring + r_begin);
-  const uint32_t row_bytes = (uint32_t)ld * 8u;   // rows_per_wg * ld * 8 < 2^32 (launcher)
-  const uint32_t off0 = t * 16u;
-  const int full = nrows / RB;
-
-  for (int idx = threadIdx.x; idx < K * CH; idx += 512) {
-    const int sidx = idx / CH, r = idx % CH;
-    sh_col[sidx][r] = (r < nrows) ? col_ring[(int64_t)sidx * mp + r_begin + r] : 0.0;
-  }
-  d2 pr[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) pr[s] = *reinterpret_cast<const d2*>(prow_ring + (int64_t)(stage * KS + s) * ld + cj);
-  d2 xb[NB][RB];
-#pragma unroll
-  for (int u = 0; u < NB; ++u)
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      xb[u][r] = d2{0.0, 0.0};
-      if (stage == 0 && u + 1 < NB && u < full) {  // uniform
-        const d2* q = reinterpret_cast<const d2*>(src_base + (off0 + (uint32_t)(u * RB + r) * row_bytes));
-        xb[u][r] = NT ? __builtin_nontemporal_load(q) : *q;
-      }
-    }
-  __syncthreads();
-  const double (*const my_col)[kSweepMaxRows] = sh_col + stage * KS;
-
-  const int nchunks = (nrows + CH - 1) / CH;
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int half = (ch & 1) * CH;
-    const bool more = ch + 1 < nchunks;   // then this chunk is a full one
-    double colpf[PF];
-    if (more) {
-      const int n_next = min(CH, nrows - (ch + 1) * CH);
-#pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int idx = threadIdx.x + k * 512;
-        const int sidx = idx / CH, r = idx % CH;
-        colpf[k] = 0.0;
-        if (r < n_next)
-          strip_load8(colpf[k], col_base, (uint32_t)(((int64_t)sidx * mp + (ch + 1) * CH + r) * 8));
-      }
-    }
-    const int b_lo = ch * (CH / RB), b_hi = min(full, b_lo + CH / RB);
-#pragma unroll 1
-    for (int bt = b_lo; bt < b_hi; bt += NB) {   // b_lo is a multiple of NB: buffer u holds batch bt + u
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int it = bt + u;   // round `it`: stage 0 works on batch it, stage 1 on batch it - 1
-        if (it < b_hi) {  // uniform
-          if (stage == 0) {
-            const int r0 = it * RB;
-            const bool ahead = it + NB - 1 < full;   // uniform
-            if (ahead) {
-#pragma unroll
-              for (int r = 0; r < RB; ++r)
-                strip_load16(xb[(u + NB - 1) % NB][r], src_base, off0 + (uint32_t)(r0 + (NB - 1) * RB + r) * row_bytes, NT);
-            }
-            if (it >= NB - 1) {
-              // younger than this batch's loads: the RB loads of each of the NB - 1 batches behind it (this stage
-              // stores nothing; parked multiplier requests in between only make the wait stricter)
-              strip_wait4<RB * (NB - 1)>(xb[u], ahead);
-            }
-            sweep_apply<KS, RB, kSweepAll>(xb[u], pr, my_col, KS, half + r0 % CH);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) sh_x[it & 1][r][t] = xb[u][r];
-          } else if (it >= 1) {
-            const int r0 = (it - 1) * RB;
-            const int half1 = (((it - 1) / (CH / RB)) & 1) * CH;
-#pragma unroll
-            for (int r = 0; r < RB; ++r) xb[u][r] = sh_x[(it - 1) & 1][r][t];   // (this stage's buffers are free)
-            sweep_apply<KS, RB, kSweepAll>(xb[u], pr, my_col, KS, half1 + r0 % CH);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-              d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
-              if (NT) __builtin_nontemporal_store(xb[u][r], q); else *q = xb[u][r];
-            }
-          }
-          __syncthreads();
-        }
-      }
-    }
-    if (more) {
-      // >= 44 memory operations were issued after the multiplier requests (48 loads by stage 0; the stores of 11 or
-      // 12 batches by stage 1): they are long back (vmcnt counts in issue order)
-      strip_wait_parked<32, PF>(colpf);
-#pragma unroll
-      for (int k = 0; k < PF; ++k) {
-        const int idx = threadIdx.x + k * 512;
-        sh_col[idx / CH][(CH - half) + idx % CH] = colpf[k];
-      }
-      __syncthreads();
-    }
-  }
-  if (stage == 1 && full >= 1) {   // the last batch handed over
-    const int r0 = (full - 1) * RB;
-    const int half1 = (((full - 1) / (CH / RB)) & 1) * CH;
-#pragma unroll
-    for (int r = 0; r < RB; ++r) xb[0][r] = sh_x[(full - 1) & 1][r][t];
-    sweep_apply<KS, RB, kSweepAll>(xb[0], pr, my_col, KS, half1 + r0 % CH);
-#pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      d2* q = reinterpret_cast<d2*>(tile_base + (off0 + (uint32_t)(r0 + r) * row_bytes));
-      if (NT) __builtin_nontemporal_store(xb[0][r], q); else *q = xb[0][r];
-    }
-  }
-}
+#ifdef LPX_WITH_VARIANTS   // superseded / experiment kernels: csrc/variants/, built by `make variants` only
+#define LPX_VARIANT_PART 5
+#include "variants/lpx_variants.inc"
+#undef LPX_VARIANT_PART
+#endif
 
 // One pivot applied to one value with the reference's full case analysis (LPState.java:139-164): the value at
 // row i, column j before pivot r -> after pivot r.
@@ -4349,7 +3586,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
                                                      const LpxCtl* __restrict__ ring, int kmax,
                                                      const double* b_src, long long* __restrict__ clk) {
   static_assert(kBlockMax <= 64, "one lane per pending pivot in the hit ballots");
-  if (clk && blockIdx.x < 64 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+  if (clk && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     const unsigned x = xcc_id() & 7u;
     clk[x * 4 + 2] = __builtin_amdgcn_s_memtime(); clk[x * 4 + 3] = wall_clock64();
   }
@@ -4770,7 +4007,11 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
   // counts workgroups of ONE per CU, which holds for both kernels)
   // (shards: the two-hop exchange is grafted onto k_block_chain2 too; the opt-in one-hop form keeps k_block_chain_t.  Their
   // grid is the caller's, identical on every device — a shard waits for one arrival word per workgroup of the owner)
+#ifdef LPX_WITH_VARIANTS
   const bool form2 = B.chain_form == 1 && (mg == nullptr || !mg->onehop);
+#else   // (chain_form = 0 on one device names round 3's kernel: the variants library only)
+  const bool form2 = mg == nullptr || (B.chain_form == 1 && !mg->onehop);
+#endif
   if (form2 && mg == nullptr) {
     const int64_t rows_wgs = (m + kChain2Threads - 1) / kChain2Threads;
     const int64_t cols_wgs = (std::max<int64_t>(B.ld - 256, 0) + kChain2Threads - 1) / kChain2Threads + 1;
@@ -4815,16 +4056,23 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
     if (form2) {
       if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, true>), dim3(G), dim3(kChain2Threads), 0, s, P);
       else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, true>), dim3(G), dim3(kChain2Threads), 0, s, P);
-    } else if (wide) hipLaunchKernelGGL((k_block_chain_t<true, 64>), dim3(G), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(G), dim3(256), 0, s, P);
+    } else hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(G), dim3(256), 0, s, P);   // (shards decide at most kShardBlockMax = 32 per block)
   } else if (form2) {
     P.m_global = m; P.n_dev = 1;
+#ifdef LPX_CHAIN2_ONE_XCD
+    G = std::min(G, 32);
+    if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, false>), dim3(8 * G), dim3(kChain2Threads), 0, s, P);
+    else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, false>), dim3(8 * G), dim3(kChain2Threads), 0, s, P);
+#else
     if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, false>), dim3(G), dim3(kChain2Threads), 0, s, P);
     else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, false>), dim3(G), dim3(kChain2Threads), 0, s, P);
+#endif
   } else {
+#ifdef LPX_WITH_VARIANTS
     P.m_global = m; P.n_dev = 1;
     if (wide) hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(G), dim3(256), 0, s, P);
     else hipLaunchKernelGGL((k_block_chain_t<false, 32>), dim3(G), dim3(256), 0, s, P);
+#endif
   }
   return G;
 }
@@ -4867,30 +4115,36 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
 #define LPX_PRE_DMA(NT_, OOP_) \
   hipLaunchKernelGGL((k_sweep32_dma<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 2, 1, 1, R.zeros, 0);
   LPX_EACH_NT_OOP(LPX_PRE_T2) LPX_EACH_NT_OOP(LPX_PRE_T4) LPX_EACH_NT_OOP(LPX_PRE_T8) LPX_EACH_NT_OOP(LPX_PRE_T16)
-  LPX_EACH_NT_OOP(LPX_PRE_T32) LPX_EACH_NT_OOP(LPX_PRE_MULTI) LPX_EACH_NT_OOP(LPX_PRE_STEADY) LPX_EACH_NT_OOP(LPX_PRE_PIPE)
-  LPX_EACH_NT_OOP(LPX_PRE_DMA)
+  LPX_EACH_NT_OOP(LPX_PRE_T32) LPX_EACH_NT_OOP(LPX_PRE_MULTI)
+#ifdef LPX_WITH_VARIANTS
+  LPX_EACH_NT_OOP(LPX_PRE_STEADY) LPX_EACH_NT_OOP(LPX_PRE_PIPE) LPX_EACH_NT_OOP(LPX_PRE_DMA)
+#endif
 #define LPX_PRE_PULL(NT_, OOP_) \
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 1, R.col_packed, R.tickets);
   if (R.tickets && R.col_packed) {   // m_local = 0: the first ticket already names nothing
     LPX_EACH_NT_OOP(LPX_PRE_PULL)
     hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr);
     hipLaunchKernelGGL(k_pack_multipliers<64>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr);
+#ifdef LPX_WITH_VARIANTS
 #define LPX_PRE_PULL64(NT_, OOP_) \
     hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, (sweep_fail_word)(R, ld));
     LPX_EACH_NT_OOP(LPX_PRE_PULL64)
 #undef LPX_PRE_PULL64
+#endif
 #define LPX_PRE_ONE64(NT_, OOP_) \
     hipLaunchKernelGGL((k_sweep64_one<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
     LPX_EACH_NT_OOP(LPX_PRE_ONE64)
 #undef LPX_PRE_ONE64
 #if LPX_FUSED
     hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr, 0);
+#ifdef LPX_WITH_VARIANTS
 #define LPX_PRE_MFMA64(NT_, OOP_) \
     hipLaunchKernelGGL((k_sweep64_mfma<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
     LPX_EACH_NT_OOP(LPX_PRE_MFMA64)
 #undef LPX_PRE_MFMA64
+#endif
 #define LPX_PRE_MFMA642(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, -1);
+    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
     LPX_EACH_NT_OOP(LPX_PRE_MFMA642)
 #undef LPX_PRE_MFMA642
 #endif
@@ -4913,8 +4167,10 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
   P.ctl = B.ctl; P.up = R.up; P.nb = 0;
   P.bar = R.chain_bar; P.bar_next = R.chain_bar + 32;
   P.spin_max = 1u << 22;
+#ifdef LPX_WITH_VARIANTS
   hipLaunchKernelGGL((k_block_chain_t<false, 32>), dim3(1), dim3(256), 0, s, P);
   hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(1), dim3(256), 0, s, P);
+#endif
   hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(1), dim3(256), 0, s, P);
   hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, false>), dim3(1), dim3(kChain2Threads), 0, s, P);
   hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, false>), dim3(1), dim3(kChain2Threads), 0, s, P);
@@ -4927,7 +4183,7 @@ int chain_blocks_per_cu() {
   int nw = 0;
   int n2 = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_block_chain_t<true, 32>), 256, 0) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, (k_block_chain_t<false, 64>), 256, 0) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nw, (k_block_chain2_t<32, kChain2Threads, false>), kChain2Threads, 0) != hipSuccess ||
       hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, (k_block_chain2_t<64, kChain2Threads, true>), kChain2Threads, 0) != hipSuccess) {
     (void)hipGetLastError();
     nb = nw = n2 = 1;
@@ -4964,47 +4220,6 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
 #undef LPX_LAUNCH_SWEEP
 }
 
-// the steady-state kernel over the full strips (a no-op unless all 32 pivots of the block are valid)
-static void launch_sweep_steady(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
-                                const double* A_src, hipStream_t s) {
-  const int nstrips_full = (int)(B.ld / 512);
-  const int ngroups = (m_local + rows_per_wg - 1) / rows_per_wg;
-  const dim3 grid(nstrips_full * ngroups), block(256);
-#define LPX_LAUNCH_STEADY(NT_, OOP_)                                                                                \
-  hipLaunchKernelGGL((k_sweep32_steady<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
-                     R.up, kmax, rows_per_wg, nstrips_full)
-  if (A_src) { if (nt) LPX_LAUNCH_STEADY(true, true); else LPX_LAUNCH_STEADY(false, true); }
-  else { if (nt) LPX_LAUNCH_STEADY(true, false); else LPX_LAUNCH_STEADY(false, false); }
-#undef LPX_LAUNCH_STEADY
-}
-
-// the LDS-DMA form of the same kernel (round 3).  rows_per_wg > 0: contiguous runs of that many rows, as
-// k_sweep32_steady; rows_per_wg <= 0: every G-th batch of 4 rows, G = workgroups per strip chosen so that the whole
-// grid is resident at once (`slots` = two workgroups per CU the stream may use) — see the kernel.
-static void launch_sweep_dma(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
-                             const double* A_src, hipStream_t s, int slots = 512, int xcd_remap = 1) {
-  const int nstrips_full = (int)(B.ld / 512);
-  const int nct = (m_local / 4 + 7) / 8;   // chunks of 32 rows
-  int ngroups, cstart, cstep;
-  if (rows_per_wg > 0) {
-    cstart = std::max(1, (rows_per_wg + 31) / 32);
-    cstep = 1;
-    ngroups = (nct + cstart - 1) / cstart;
-  } else {
-    ngroups = std::max(1, std::min(nct, slots / std::max(1, nstrips_full)));
-    cstart = 1;
-    cstep = ngroups;
-  }
-  const int groups_launched = xcd_remap ? (ngroups + 7) / 8 * 8 : ngroups;   // (surplus workgroups return at once)
-  const dim3 grid(nstrips_full * groups_launched), block(256);
-#define LPX_LAUNCH_DMA(NT_, OOP_)                                                                                \
-  hipLaunchKernelGGL((k_sweep32_dma<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
-                     R.up, kmax, cstart, cstep, nstrips_full, R.zeros, xcd_remap)
-  if (A_src) { if (nt) LPX_LAUNCH_DMA(true, true); else LPX_LAUNCH_DMA(false, true); }
-  else { if (nt) LPX_LAUNCH_DMA(true, false); else LPX_LAUNCH_DMA(false, false); }
-#undef LPX_LAUNCH_DMA
-}
-
 // every wave on its own, batches pulled from per-sub-strip ticket counters (R.tickets: zeroed here, on the stream);
 // the grid is what is resident: G workgroups per strip, G x strips <= slots (two workgroups per CU the stream may use)
 static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
@@ -5021,25 +4236,6 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
   if (A_src) { if (nt) LPX_LAUNCH_PULL(true, true); else LPX_LAUNCH_PULL(false, true); }
   else { if (nt) LPX_LAUNCH_PULL(true, false); else LPX_LAUNCH_PULL(false, false); }
 #undef LPX_LAUNCH_PULL
-}
-
-// blocks of 33..64: pairs of waves, batches pulled from the same per-sub-strip counters; G workgroups (two pairs each)
-// per pair of sub-strips
-static void launch_sweep64_pull(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                                hipStream_t s, int slots = 512) {
-  const int nstrips_full = (int)(B.ld / 512);
-  const int npairs = nstrips_full * 2;
-  const int nbt = m_local / 4;
-  const int G = std::max(1, std::min(nbt, slots / std::max(1, npairs)));
-  hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed,
-                     R.tickets, nstrips_full * 4, R.clk);
-  const dim3 grid(npairs * G), block(256);
-#define LPX_LAUNCH_PULL64(NT_, OOP_)                                                                              \
-  hipLaunchKernelGGL((k_sweep64_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                     nstrips_full, R.col_packed, R.tickets, (sweep_fail_word)(R, B.ld))
-  if (A_src) { if (nt) LPX_LAUNCH_PULL64(true, true); else LPX_LAUNCH_PULL64(false, true); }
-  else { if (nt) LPX_LAUNCH_PULL64(true, false); else LPX_LAUNCH_PULL64(false, false); }
-#undef LPX_LAUNCH_PULL64
 }
 
 // blocks of 33..64 by single waves on 64-column sub-strips (k_sweep64_one); G workgroups per group of four sub-strips
@@ -5072,22 +4268,18 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
   hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, s, R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
                      R.tickets, nstrips_full * 8, R.clk, two_waves ? 1 : 0);
   if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
-#ifdef LPX_DIAG_BUILD   // timing experiments only (every tile reads tile 0's multipliers: results are wrong): never in the release library
-    static const int a_mask = getenv("LPX_SWEEP_DIAG") && atoi(getenv("LPX_SWEEP_DIAG")) == 1 ? 0 : -1;
-#else
-    const int a_mask = -1;
-#endif
     const int ng2 = nstrips_full * 4;
     const int G2 = std::max(1, std::min(ntiles, 2 * slots / std::max(1, ng2)));
     const dim3 grid2(ng2 * G2), block2(256);
 #define LPX_LAUNCH_MFMA642(NT_, OOP_)                                                                               \
     hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), grid2, block2, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                       nstrips_full, R.col_packed, R.tickets, a_mask)
+                       nstrips_full, R.col_packed, R.tickets)
     if (A_src) { if (nt) LPX_LAUNCH_MFMA642(true, true); else LPX_LAUNCH_MFMA642(false, true); }
     else { if (nt) LPX_LAUNCH_MFMA642(true, false); else LPX_LAUNCH_MFMA642(false, false); }
 #undef LPX_LAUNCH_MFMA642
     return;
   }
+#ifdef LPX_WITH_VARIANTS   // k_sweep64_mfma (first version, one wave per SIMD): sweep_form = 4 of the variants library
   const dim3 grid(ngroups * G), block(256);
 #define LPX_LAUNCH_MFMA64(NT_, OOP_)                                                                               \
   hipLaunchKernelGGL((k_sweep64_mfma<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
@@ -5095,26 +4287,12 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
   if (A_src) { if (nt) LPX_LAUNCH_MFMA64(true, true); else LPX_LAUNCH_MFMA64(false, true); }
   else { if (nt) LPX_LAUNCH_MFMA64(true, false); else LPX_LAUNCH_MFMA64(false, false); }
 #undef LPX_LAUNCH_MFMA64
+#else
+  (void)G;
+#endif
 }
 #endif
 
-static void launch_sweep64_pipe(const Buffers& B, const BlockRing& R, int m_local, int kmax, int rows_per_wg, bool nt,
-                                const double* A_src, hipStream_t s) {
-  const int nstrips_full = (int)(B.ld / 512);
-  const int ngroups = (m_local + rows_per_wg - 1) / rows_per_wg;
-  const dim3 grid(nstrips_full * ngroups), block(512);
-#define LPX_LAUNCH_PIPE(NT_, OOP_)                                                                                  \
-  hipLaunchKernelGGL((k_sweep64_pipe<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
-                     R.up, kmax, rows_per_wg, nstrips_full)
-  if (A_src) { if (nt) LPX_LAUNCH_PIPE(true, true); else LPX_LAUNCH_PIPE(false, true); }
-  else { if (nt) LPX_LAUNCH_PIPE(true, false); else LPX_LAUNCH_PIPE(false, false); }
-#undef LPX_LAUNCH_PIPE
-}
-
-// Rows per workgroup of the sweep (a multiple of its 64-row chunk).  A workgroup pays its prologue (the 2K doubles of
-// pivot-row slices per thread, ~K x 1.5 rows' worth of traffic) once per run, so runs should be long; but the grid
-// is dealt in rounds of `slots` workgroups (two per CU the stream may use) and the last round should be full.
-// Chosen by cost = rounds x (rows + prologue): several rounds of long runs.
 static int choose_sweep_rows(int m_local, int64_t ld, int K, int cus) {
   const int64_t nstrips = (ld + 511) / 512;
   const int64_t slots = std::max(1, 2 * cus);
@@ -5134,30 +4312,6 @@ static int choose_sweep_rows(int m_local, int64_t ld, int K, int cus) {
   return best_rows;
 }
 
-// Rows per workgroup of the two-stage kernel: one 512-thread workgroup per CU at a time, so the grid should be a
-// whole number of rounds of `cus` workgroups (cfg4 alone on the chip: 1024 rows = 4 full rounds 2.83 ms, 672 rows =
-// 6.1 rounds 3.29 ms); three or more rounds when there is enough work, so that uneven CUs even out.
-// `slots` = workgroups resident at once (one per CU for the two-stage kernel, two for k_sweep32_steady, whose runs
-// take ~0.6 ms each at cfg4: 2.86 rounds of 832-row runs cost what 3 rounds do, 1.80 ms, where 3 exact rounds of
-// 784-row runs take 1.70 ms).
-static int choose_pipe_rows(int m_local, int nstrips_full, int slots, int prologue_rows = 96) {
-  // prologue_rows: the run's pivot-row slices and first multipliers, in rows' worth of time
-  int best_rows = std::max(4, (m_local + 3) / 4 * 4);
-  int64_t best_cost = INT64_MAX;
-  const int cus = std::max(1, slots);
-  for (int rounds = 1; rounds <= 8; ++rounds) {
-    const int64_t groups = std::max<int64_t>(1, (int64_t)rounds * cus / std::max(1, nstrips_full));
-    const int rows = (int)(((m_local + groups - 1) / groups + 3) / 4 * 4);
-    if (rows < 48 && rounds > 1) break;
-    const int64_t used = ((int64_t)(m_local + rows - 1) / rows * nstrips_full + cus - 1) / cus;   // rounds really needed
-    int64_t cost = used * (rows + prologue_rows);
-    if (rounds < 3) cost += cost / 16;   // no slack for uneven CUs
-    if (cost < best_cost) { best_cost = cost; best_rows = rows; }
-  }
-  return best_rows;
-}
-
-// rows_per_wg <= 0: chosen here (see choose_sweep_rows); cus: CUs the stream may use (0: the whole device)
 const char* sweep_kernel_name(int code) {
   switch (code) {
     case kSweepTiles: return "k_update_tiles";
@@ -5174,6 +4328,13 @@ const char* sweep_kernel_name(int code) {
   }
 }
 
+#ifdef LPX_WITH_VARIANTS
+#define LPX_VARIANT_PART 6
+#include "variants/lpx_variants.inc"
+#undef LPX_VARIANT_PART
+#endif
+
+// rows_per_wg <= 0: chosen here (see choose_sweep_rows); cus: CUs the stream may use (0: the whole device)
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep,
                        int cus, int form, int* kernel_used) {
@@ -5198,33 +4359,45 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     rows_per_wg = rows_per_tile;
     used = kSweepTiles;
   } else if (K > 32) {
-    // blocks of up to 64 pivots.  A full block of 64 over the full strips goes through the two-stage kernel in one
-    // pass; whatever that leaves (a block that ended early or has fewer than 64 decisions, the partial last strip,
-    // m not a multiple of 4) takes two passes of the generic kernel: slots 0..31 (out of place when asked), then
-    // slots 32.. in place on the result.  An entry's update reads ring values only, so the split changes nothing.
+    // blocks of up to 64 pivots.  A block of 33..64 valid pivots over the full strips goes through a 64-step kernel in one
+    // pass (k_sweep64_one: one wave per 64-column sub-strip; in the fused arithmetic with 16-row tiles k_sweep64_mfma2, the
+    // matrix cores); whatever that leaves (a block that ended early, the partial last strip, m not a multiple of 4) takes
+    // two passes of the generic kernel: slots 0..31 (out of place when asked), then slots 32.. in place on the result.
+    // An entry's update reads ring values only, so the split changes nothing.
+    // (sweep_form 1 / 2 / 4 name the superseded kernels of csrc/variants/ — k_sweep64_pipe, k_sweep64_pull, k_sweep64_mfma —
+    // and select them in the variants library only; here they mean the default.)
     const int nstrips_full = (int)(B.ld / 512);
     // (the pull kernels address a batch's rows by 32-bit byte offsets: 3 * ld * 8 + 1 KiB must stay below 2^32)
     const bool geom = m_local % 4 == 0 && nstrips_full >= 1 && 3 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
+#ifdef LPX_WITH_VARIANTS
     const bool pull = geom && form != 1 && R.tickets && R.col_packed;   // round 3 / 4: blocks of 33..64 valid pivots
     const bool pipe = geom && !pull && K == 64;                         // round 2: full blocks of 64 only
-    // round 4: one wave per 64-column sub-strip (form 0, the default); form 2: the pair of waves of round 3
     const bool one = pull && form != 2;
-    // round 4, fused arithmetic: the matrix cores (16-row tiles): form 0 = k_sweep64_mfma2 (two waves per SIMD, B operands
-    // in LDS: 2.12 vs 2.33 ms per 64 pivots at cfg4), form 4 = k_sweep64_mfma (one wave per SIMD); form 3 = k_sweep64_one there
+    const bool mfma_form = form == 0 || form == 4;
+    const bool mfma2 = form == 0;
+#else
+    const bool pull = geom && R.tickets && R.col_packed;
+    const bool pipe = false;
+    const bool one = pull;
+    const bool mfma_form = form != 3;   // (3: k_sweep64_one in the fused arithmetic too)
+    const bool mfma2 = true;
+#endif
     bool mfma = false;
 #if LPX_FUSED
-    mfma = one && (form == 0 || form == 4) && m_local % 16 == 0 && 16 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
+    mfma = one && mfma_form && m_local % 16 == 0 && 16 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
 #endif
     int rows64 = 0;
     if (mfma) {
 #if LPX_FUSED
-      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, form == 0);   // form 4: one wave per SIMD (k_sweep64_mfma)
+      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, mfma2);
 #endif
       rows64 = 16;
     } else if (one) {
       launch_sweep64_one(B, R, m_local, K, nt, A_src, s, 2 * cus);
       rows64 = 4;
-    } else if (pull) {
+    }
+#ifdef LPX_WITH_VARIANTS
+    else if (pull) {
       launch_sweep64_pull(B, R, m_local, K, nt, A_src, s, 2 * cus);
       rows64 = 4;
     } else if (pipe) {
@@ -5232,22 +4405,20 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
       while (rows64 > 4 && (int64_t)rows64 * B.ld * 8 >= (int64_t)1 << 32) rows64 -= 4;  // 32-bit offsets
       launch_sweep64_pipe(B, R, m_local, K, rows64, nt, A_src, s);
     }
+#endif
     // what the one-pass kernel does not take (the partial last strip; a block with fewer valid pivots than it wants:
-    // < 33 for the pull form, < 64 for the two-stage pipe) goes through two passes of the generic kernel
+    // < 33 for the pull forms, < 64 for the two-stage pipe) goes through two passes of the generic kernel
     const int complement = pull ? 34 : (pipe ? 65 : 0);
     int rows = choose_sweep_rows(m_local, B.ld, 32, cus);
     while (rows > kSweepChunk && (int64_t)rows * B.ld * 8 >= (int64_t)1 << 32) rows -= kSweepChunk;
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, complement, 0);
     launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, complement, 32);
     rows_per_wg = (pull || pipe) ? rows64 : rows;
-    used = mfma ? (form == 0 ? kSweepMfma642 : kSweepMfma64) : one ? kSweepOne64 : (pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti));
-#ifndef LPX_STEADY_PARTIAL
-#define LPX_STEADY_PARTIAL 1
-#endif
-  } else if (K < kMaxBlock && !(LPX_STEADY_PARTIAL && m_local % 4 == 0 && B.ld >= 512)) {
-    // a partly filled block of 17..31 pivots (the tail of a pivot budget) where the hand-pipelined kernel does not
-    // apply: the tile kernel's guarded path took such blocks faster than the long-run kernel's (cfg3, 20 pivots, same
-    // box: 490 vs 615 us); 64-row tiles as long as the grid keeps a few thousand workgroups (profiles/r01_sweep_rows.txt)
+    used = mfma ? (mfma2 ? kSweepMfma642 : kSweepMfma64) : one ? kSweepOne64 : (pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti));
+  } else if (K < kMaxBlock && !(m_local % 4 == 0 && B.ld >= 512)) {
+    // a partly filled block of 17..31 pivots (the tail of a pivot budget) where the pulled kernel does not apply: the tile
+    // kernel's guarded path took such blocks faster than the long-run kernel's (cfg3, 20 pivots, same box: 490 vs 615 us);
+    // 64-row tiles as long as the grid keeps a few thousand workgroups (profiles/r01_sweep_rows.txt)
     const int64_t nstrips = (B.ld + 511) / 512;
     int rows_per_tile = 16;
     for (int rows : {64, 32})
@@ -5257,49 +4428,50 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     rows_per_wg = rows_per_tile;
     used = kSweepTiles;
   } else {
-    // long runs of rows per workgroup (k_update_multi): the 2K doubles of pivot-row slices are fetched once per run
-    const bool rows_given = rows_per_wg > 0;
+    // blocks of 17..32.  Long runs of rows per workgroup (k_update_multi) where the pulled kernel does not apply; otherwise
+    // k_sweep32_pull over the full strips (LDS-DMA staging, every wave pulls its batches in address order) and the generic
+    // kernel for the partial last strip.  (sweep_form 1 / 2: k_sweep32_steady / k_sweep32_dma of the variants library.)
     if (rows_per_wg <= 0) rows_per_wg = choose_sweep_rows(m_local, B.ld, K, cus);
     rows_per_wg = std::max(kSweepChunk, (rows_per_wg + kSweepChunk - 1) / kSweepChunk * kSweepChunk);
     while (rows_per_wg > kSweepChunk && (int64_t)rows_per_wg * B.ld * 8 >= (int64_t)1 << 32) rows_per_wg -= kSweepChunk;  // 32-bit offsets
-#ifndef LPX_NO_STEADY_SWEEP
-    if (m_local % 4 == 0 && B.ld >= 512) {
-      // full block over the full strips: hand-pipelined kernel (48-row chunks); the rest — a block that ends early,
-      // the partial last strip — by the generic kernel, which skips what the first one took
-#ifndef LPX_STEADY_EXACT_ROUNDS
-#define LPX_STEADY_EXACT_ROUNDS 1
-#endif
-      int rows48 = std::max(48, rows_per_wg / 48 * 48);
-      if (LPX_STEADY_EXACT_ROUNDS && !rows_given) {   // whole rounds of two workgroups per CU over the full strips
-        rows48 = choose_pipe_rows(m_local, (int)(B.ld / 512), 2 * cus, 48);
-        while (rows48 > 4 && (int64_t)rows48 * B.ld * 8 >= (int64_t)1 << 32) rows48 -= 4;   // 32-bit offsets
-      }
-      const bool wide32 = 3 * B.ld * 8 + 1024 >= ((int64_t)1 << 32);   // 32-bit row offsets of the LDS-DMA kernels would wrap
-      if (form == 1 || wide32 || !R.zeros || !R.tickets || !R.col_packed) {   // round 2: batches parked in registers, runs of rows
-        launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
-        used = kSweepSteady;
-      } else if (form == 2) {   // LDS-DMA staging, runs of rows (diagnostics: the step between the two)
+    const bool wide32 = 3 * B.ld * 8 + 1024 >= ((int64_t)1 << 32);   // 32-bit row offsets of the LDS-DMA kernels would wrap
+    const bool pullable = m_local % 4 == 0 && B.ld >= 512 && !wide32 && R.zeros && R.tickets && R.col_packed;
+    bool done = false;
+#ifdef LPX_WITH_VARIANTS
+    if (m_local % 4 == 0 && B.ld >= 512 && (form == 1 || form == 2 || !pullable)) {
+      int rows48 = choose_pipe_rows(m_local, (int)(B.ld / 512), 2 * cus, 48);
+      while (rows48 > 4 && (int64_t)rows48 * B.ld * 8 >= (int64_t)1 << 32) rows48 -= 4;   // 32-bit offsets
+      if (form == 2 && pullable) {   // LDS-DMA staging, runs of rows (the step between the two)
         launch_sweep_dma(B, R, m_local, K, rows48, nt, A_src, s, 2 * cus);
         used = kSweepDma;
-      } else {                  // default: LDS-DMA staging, every wave pulls its batches in address order
-        launch_sweep_pull(B, R, m_local, K, nt, A_src, s, 2 * cus);
-        used = kSweepPull;
-        rows48 = 4;             // (what lpx_state_get_info reports as the run length: one batch)
+      } else {                       // round 2: batches parked in registers, runs of rows
+        launch_sweep_steady(B, R, m_local, K, rows48, nt, A_src, s);
+        used = kSweepSteady;
       }
       if (B.ld % 512 != 0) launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);   // the partial last strip
-      rows_per_wg = rows48;   // (what lpx_state_get_info reports: the kernel that did the work)
-    } else
+      rows_per_wg = rows48;
+      done = true;
+    }
 #endif
-    {
+    if (!done && pullable) {
+      launch_sweep_pull(B, R, m_local, K, nt, A_src, s, 2 * cus);
+      used = kSweepPull;
+      if (B.ld % 512 != 0) launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);   // the partial last strip
+      rows_per_wg = 4;   // (what lpx_state_get_info reports as the run length: one batch)
+    } else if (!done) {
       launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s);
       used = kSweepMulti;
     }
   }
   if (kernel_used) *kernel_used = used;
   if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
+  // the clock probe: only the pack kernels of the pulled sweeps stamp in FRONT of a sweep; behind any other form the
+  // fix-up must not pair its stamp with a front stamp of an older launch (lpx_state_info.sweep_clock_mhz then says 0)
+  const bool probed = used == kSweepPull || used == kSweepPull64 || used == kSweepOne64 || used == kSweepMfma64 || used == kSweepMfma642;
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   hipLaunchKernelGGL(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
-                     R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, R.clk);
+                     R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, probed ? R.clk : nullptr);
+  if (!probed && R.clk) (void)hipMemsetAsync(R.clk, 0, 256, s);
   return rows_per_wg;
 }
 

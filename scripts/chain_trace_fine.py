@@ -30,8 +30,9 @@ last = 7 if tr.shape[1] == 16 else tr.shape[1] - 1     # (16 stamps: slots 0..7 
 live = tr[(tr[:, 0] != 0) & (tr[:, last] >= tr[:, last - 1])]
 seg = np.diff(live, axis=1) / 100.0
 tot = (live[:, last] - live[:, 0]) / 100.0
-print("%s %dx%d %s: grid %d, %d decisions, per decision mean %.2f median %.2f us" % (
-    wl, m, n, {k: v for k, v in opts.items() if k != "chain_trace"}, info["chain_wgs"], len(live), tot.mean(), np.median(tot)))
+print("%s %dx%d %s: grid %d (XCD mask 0x%02x), %d decisions, per decision mean %.2f median %.2f us" % (
+    wl, m, n, {k: v for k, v in opts.items() if k != "chain_trace"}, info["chain_wgs"], info["chain_xcd_mask"], len(live), tot.mean(),
+    np.median(tot)))
 if tr.shape[1] == 16:   # diagnostic build (-DLPX_CHAIN2_FINE): stamps in time order
     order = [0, 1, 8, 9, 10, 11, 2, 3, 12, 4, 13, 14, 15, 5, 6, 7]
     nm16 = ["A.loads", "A.meet", "A.chain", "A.store+ratio", "A.min", "A.win", "X", "B.min+checks", "B.loads", "B.meet",

@@ -20,7 +20,7 @@ def lps(arith):
     from tests.conftest import package_in_mode
     pkg = package_in_mode(arith)
     yield pkg
-    pkg.set_default_arithmetic("plain")
+    pkg.set_default_arithmetic("auto")
 
 
 @pytest.fixture(scope="module")

@@ -24,7 +24,7 @@ def lps(arith):
     from tests.conftest import package_in_mode
     pkg = package_in_mode(arith)
     yield pkg
-    pkg.set_default_arithmetic("plain")
+    pkg.set_default_arithmetic("auto")
 
 
 @pytest.fixture(scope="module")
@@ -913,14 +913,13 @@ def test_cfg4_onepass_forms_12_pivots_vs_fp64_oracle(lps, oracle, block):
     assert info["block"] == block and info["nontemporal"] == 1
 
 
-@pytest.mark.parametrize("form,name", [(0, "k_sweep32_pull"), (1, "k_sweep32_steady"), (2, "k_sweep32_dma")])
-def test_cfg3_sweep_forms_vs_fp64_oracle(lps, oracle, form, name):
-    """The three steady-state sweep kernels of blocks of 17..32 pivots (round 3: LDS-DMA staging with batches pulled in
-    address order; round 2: register staging; LDS-DMA with runs of rows) each through two full blocks and a tail at
-    cfg3 (a short one, which the tile kernel takes, then one of 28 pivots, which they take padded with identity steps),
-    against the fp64 oracle."""
-    info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (75, 60), options={"sweep_form": form})
-    assert info["block"] == 32 and info["sweep_kernel_name"] == name
+def test_cfg3_sweep_of_blocks_of_32_vs_fp64_oracle(lps, oracle):
+    """The steady-state sweep kernel of blocks of 17..32 pivots (k_sweep32_pull: LDS-DMA staging, batches pulled in address
+    order) through two full blocks and a tail at cfg3 (a short one, which the tile kernel takes, then one of 28 pivots, which
+    it takes padded with identity steps), against the fp64 oracle.  (The kernels it replaced — sweep_form 1 / 2 — are checked
+    the same way in tests/test_gpu_variants.py, on the variants library.)"""
+    info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (75, 60), options={"sweep_form": 0})
+    assert info["block"] == 32 and info["sweep_kernel_name"] == "k_sweep32_pull"
 
 
 def test_cfg4_timed_form_70_pivots_vs_fp64_oracle(lps, oracle, arith):
@@ -1182,11 +1181,10 @@ def test_soak_repeated_runs_on_the_shape_that_exposed_the_stale_read(lps, oracle
 
 @pytest.mark.parametrize("shape", [(1000, 2100), (4100, 1024), (8, 512), (2052, 4100)])
 @pytest.mark.parametrize("block,form,kernel", [(21, 0, "k_sweep32_pull"), (32, 0, "k_sweep32_pull"),
-                                               (40, 0, "k_sweep64_one"), (64, 0, "k_sweep64_one"),
-                                               (40, 2, "k_sweep64_pull"), (64, 2, "k_sweep64_pull")])
+                                               (40, 0, "k_sweep64_one"), (64, 0, "k_sweep64_one")])
 def test_pulled_sweep_kernels_on_ragged_shapes(lps, oracle, shape, block, form, kernel):
     """The ticket-pulling sweep kernels (one wave per 128-column sub-strip for blocks up to 32; one wave per 64-column
-    sub-strip — or, sweep_form 2, a pair of waves per 128 columns — for blocks of 33..64) on shapes with a partial last
+    sub-strip for blocks of 33..64 — these heights are no multiples of 16, so also in the fused mode) on shapes with a partial last
     strip, a last batch count that is not a multiple of anything, fewer batches than workers, and blocks that are only
     partly filled (21 of 32, 40 of 64 steps are real, the rest identities): bit-exact vs the fp64 oracle after every
     budget; the engine must report the kernel that is expected to have run."""
@@ -1228,7 +1226,7 @@ def test_blocks_of_64_in_place_and_out_of_place_with_and_without_nt(lps, oracle,
 
 
 @pytest.mark.parametrize("shape", [(1024, 2112), (2048, 4100), (4096, 1024), (16, 512)])
-@pytest.mark.parametrize("form", [0, 4])
+@pytest.mark.parametrize("form", [0, 3])
 @pytest.mark.parametrize("block", [40, 64])
 def test_blocks_of_33_to_64_with_16_row_tiles(lps, oracle, arith, shape, block, form):
     """Tableaus whose height is a multiple of 16: in the fused-arithmetic mode blocks of 33..64 go through the matrix
@@ -1237,7 +1235,7 @@ def test_blocks_of_33_to_64_with_16_row_tiles(lps, oracle, arith, shape, block, 
     fewer tiles than workers: bit-exact against the oracle of the mode after every budget."""
     m, n = shape
     A, b, c = dense_lp(m, n, seed=17 * m + n)
-    st = lps.LPState(A, b, c, block=block, options={"sweep_form": form})   # (fused: 0 = two waves per SIMD, 4 = one)
+    st = lps.LPState(A, b, c, block=block, options={"sweep_form": form})   # (0: by mode — the matrix cores when fused; 3: k_sweep64_one)
     ref = oracle.State(A, b, c, kind=oracle.FP64)
     for budget in (block - 1, 2 * block + 5, block - 1):
         status, pivots, _ = st.simplex_loop(max_pivots=budget)
@@ -1245,6 +1243,6 @@ def test_blocks_of_33_to_64_with_16_row_tiles(lps, oracle, arith, shape, block, 
         assert (status, pivots) == (want["status"], want["pivots"]), (shape, block, budget)
         assert_state_bits_equal(st.read(), ref.read(), "block %d budget %d of %s" % (block, budget, shape))
     if status == 9 and n >= 512:
-        want_kernel = ("k_sweep64_mfma2" if form == 0 else "k_sweep64_mfma") if arith == "fused" else "k_sweep64_one"
+        want_kernel = "k_sweep64_mfma2" if (arith == "fused" and form == 0) else "k_sweep64_one"   # (form 3: the vector kernel in both modes)
         assert st.info()["sweep_kernel_name"] == want_kernel, st.info()
     st.close()

@@ -16,14 +16,16 @@ SRC = os.path.join(ROOT, "linear_programming_solver_amd", "csrc", "lpx_kernels.h
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-def _compile_asm(tmp_path_factory, fused):
+def _compile_asm(tmp_path_factory, fused, variants=False):
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
         pytest.skip("hipcc not available")
-    out = tmp_path_factory.mktemp("asm%d" % fused) / "lpx_kernels.s"
-    # the flags of csrc/Makefile that matter for code generation (the file is compiled twice: LPX_FUSED = 0 / 1)
+    out = tmp_path_factory.mktemp("asm%d%d" % (fused, variants)) / "lpx_kernels.s"
+    # the flags of csrc/Makefile that matter for code generation (the file is compiled twice: LPX_FUSED = 0 / 1; the
+    # variants library adds -DLPX_WITH_VARIANTS: the superseded kernels of csrc/variants/)
     subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
-                           "-ffp-contract=off", "-Wno-unused-result", "-DLPX_FUSED=%d" % fused, "-S", "--cuda-device-only",
-                           SRC, "-o", str(out)], stderr=subprocess.DEVNULL)
+                           "-ffp-contract=off", "-Wno-unused-result", "-DLPX_FUSED=%d" % fused] +
+                          (["-DLPX_WITH_VARIANTS"] if variants else []) +
+                          ["-S", "--cuda-device-only", SRC, "-o", str(out)], stderr=subprocess.DEVNULL)
     return out.read_text()
 
 
@@ -31,6 +33,12 @@ def _compile_asm(tmp_path_factory, fused):
 def device_asm(tmp_path_factory):
     """lpxk::plain — the default arithmetic (product and difference rounded separately)."""
     return _compile_asm(tmp_path_factory, 0)
+
+
+@pytest.fixture(scope="module")
+def device_asm_variants(tmp_path_factory):
+    """lpxk::plain of the variants library (`make variants`): the product's kernels plus csrc/variants/."""
+    return _compile_asm(tmp_path_factory, 0, variants=True)
 
 
 @pytest.fixture(scope="module")
@@ -48,21 +56,32 @@ def _resources(asm, kernel):
 
 
 @pytest.mark.parametrize("kernel,max_vgpr", [("k_sweep32_steady", 256), ("k_sweep64_pipe", 256)])
-def test_hand_pipelined_sweep_kernels_have_no_scratch(device_asm, kernel, max_vgpr):
-    res = _resources(device_asm, kernel)
+def test_hand_pipelined_sweep_kernels_have_no_scratch(device_asm_variants, kernel, max_vgpr):
+    res = _resources(device_asm_variants, kernel)
     assert len(res) == 4, sorted(res)   # <NT, OOP> x 2 x 2
     for name, r in res.items():
         assert r["private_seg_size"] == 0, (name, r)
         assert r["num_agpr"] == 0 and r["num_vgpr"] <= max_vgpr, (name, r)   # two waves per SIMD, nothing parked in AGPRs
 
 
-def test_default_decision_kernel_has_no_scratch(device_asm):
-    """The 32-slot decision kernel (the default loop) keeps its register arrays in registers: no scratch traffic on
-    its latency-bound path.  (The opt-in 64-slot form spills a little; it is not checked here.)"""
-    res = {k: v for k, v in _resources(device_asm, "k_block_chain_t").items() if "Li32E" in k}
-    assert len(res) == 2, sorted(res)   # one device / shards of an lpx_multi
+def test_one_hop_decision_kernel_has_no_scratch(device_asm):
+    """k_block_chain_t<true, 32> (round 3's decision kernel: in the product only for the opt-in one-hop exchange of the
+    shards) keeps its register arrays in registers; the one-device instantiations live in the variants library."""
+    res = _resources(device_asm, "k_block_chain_t")
+    assert len(res) == 1 and all("Lb1ELi32E" in k for k in res), sorted(res)
     for name, r in res.items():
         assert r["private_seg_size"] == 0, (name, r)
+
+
+def test_product_library_has_no_superseded_kernels(device_asm, device_asm_fused, device_asm_variants):
+    """VERDICT r04, Next 7: the sweep kernels that lost their A/Bs are not compiled into liblpx.so; the variants library
+    still has them (tests/test_gpu_variants.py checks their bits on the GPU)."""
+    gone = ("k_sweep32_steady", "k_sweep32_dma", "k_sweep64_pull", "k_sweep64_pipe", "k_sweep64_mfmaI", "k_sweep64_mfma2_diag")
+    for asm in (device_asm, device_asm_fused):
+        for k in gone:
+            assert not re.search(r"\.amdhsa_kernel \S*%s" % k, asm), k
+    for k in ("k_sweep32_steady", "k_sweep32_dma", "k_sweep64_pull", "k_sweep64_pipe"):
+        assert re.search(r"\.amdhsa_kernel \S*%s" % k, device_asm_variants), k
 
 
 def _kernel_bodies(asm, kernel):
@@ -74,8 +93,18 @@ def _kernel_bodies(asm, kernel):
     return out
 
 
+def _kernel_functions(asm, kernel):
+    """like _kernel_bodies, but the WHOLE function (a kernel with early returns has several s_endpgm)."""
+    out = {}
+    for m in re.finditer(r"^(\S*%s\S*):\s*(?:;.*)?$" % kernel, asm, flags=re.M):
+        end = asm.find(".Lfunc_end", m.end())
+        out[m.group(1)] = [ln.strip() for ln in asm[m.end():end].splitlines()]
+    return out
+
+
 @pytest.mark.parametrize("kernel", ["k_sweep32_steady", "k_sweep64_pipe"])
-def test_no_register_copy_sits_in_front_of_a_hand_written_wait(device_asm, kernel):
+def test_no_register_copy_sits_in_front_of_a_hand_written_wait(device_asm_variants, kernel):
+    device_asm = device_asm_variants
     """The hand-written `s_waitcnt vmcnt(N)` must come before ANY copy of the registers its loads are landing in.
     (A single asm with the registers as in/out operands let the allocator copy them in front of the statement: one
     wave's last batches of a run then came out stale once in ~15 000 workgroup runs.)  Within a basic block, between
@@ -117,7 +146,8 @@ def _regs(operand):
 
 
 @pytest.mark.parametrize("kernel", ["k_sweep32_steady", "k_sweep64_pipe"])
-def test_no_register_copy_reads_a_hand_issued_load_before_its_wait(device_asm, kernel):
+def test_no_register_copy_reads_a_hand_issued_load_before_its_wait(device_asm_variants, kernel):
+    device_asm = device_asm_variants
     """The other half of the same hazard: after a hand-issued `global_load` nothing may read its destination
     registers before a hand-written wait has been passed.  Checked in program order (the kernels' loops keep loads
     and the wait that covers them in straight succession): between an asm load and the next asm `s_waitcnt vmcnt`
@@ -152,7 +182,8 @@ def test_no_register_copy_reads_a_hand_issued_load_before_its_wait(device_asm, k
 
 # ---- round 3: the LDS-DMA sweep kernels -------------------------------------------------------------------------------
 @pytest.mark.parametrize("kernel", ["k_sweep32_dma", "k_sweep32_pull", "k_sweep64_pull", "k_sweep64_one"])
-def test_lds_dma_sweep_kernels_have_no_scratch(device_asm, kernel):
+def test_lds_dma_sweep_kernels_have_no_scratch(device_asm_variants, kernel):
+    device_asm = device_asm_variants
     """Their tableau loads land in LDS, not in registers, but the pivot-row slices (128 VGPRs) must stay in registers
     and two workgroups must fit a CU: no scratch, no AGPRs, at most 256 VGPRs, LDS <= 80 KiB."""
     res = _resources(device_asm, kernel)
@@ -165,7 +196,8 @@ def test_lds_dma_sweep_kernels_have_no_scratch(device_asm, kernel):
 
 
 @pytest.mark.parametrize("kernel", ["k_sweep32_pull", "k_sweep64_pull", "k_sweep64_one"])
-def test_pulled_tickets_are_not_touched_before_they_are_taken(device_asm, kernel):
+def test_pulled_tickets_are_not_touched_before_they_are_taken(device_asm_variants, kernel):
+    device_asm = device_asm_variants
     """The pull kernels' only hand-issued operation with a register destination is the ticket atomic.  Between the asm
     statement that issues it and the v_readfirstlane that takes the ticket (behind a hand-written s_waitcnt vmcnt and
     a scheduling barrier) no compiler-generated instruction may name that register — a copy made earlier would carry
@@ -207,22 +239,36 @@ def test_pulled_tickets_are_not_touched_before_they_are_taken(device_asm, kernel
 
 
 # ---- round 4 ---------------------------------------------------------------------------------------------------------
-def test_round4_decision_kernel_keeps_its_arrays_in_registers(device_asm, device_asm_fused):
-    """k_block_chain2_t<32, 256> (the default decision kernel of the one-device loop) in both compilations: one wave per
-    SIMD, its register arrays in VGPRs / AGPRs.  At most a few dozen bytes of scratch (one 16-byte pair spilled around
-    the rare full exchange at the end of a decision), nothing on the hand-off path: every scratch access sits behind the
-    last poll of workgroup 0's record."""
-    for asm in (device_asm, device_asm_fused):
-        res = {k: v for k, v in _resources(asm, "k_block_chain2_t").items() if "Li32E" in k}
-        assert len(res) == 1, sorted(res)
+def test_decision_kernel_has_no_scratch_and_a_branch_free_ladder(device_asm, device_asm_fused):
+    """k_block_chain2_t (the decision kernel of the blocked loop; one device and shards, 32- and 64-slot rings) in both
+    compilations: one wave per SIMD, ONE window of live chunks in registers — no scratch in any instantiation (round 4's
+    64-slot form held its whole ring: 404 registers, and spilled with the new ladder).  The pending-pivot ladder is inline
+    asm: between an ASMSTART / ASMEND pair of a ladder chunk there are only the multiply-adds (fused: v_fma_f64; default:
+    v_mul_f64 + v_add_f64), the eight v_cmp and the s_mov of EXEC — no branch, no select, no wait."""
+    for asm, fused in ((device_asm, False), (device_asm_fused, True)):
+        res = _resources(asm, "k_block_chain2_t")
+        assert len(res) == 4, sorted(res)   # <32 | 64, 256, one device | shards>
         for name, r in res.items():
-            assert r["private_seg_size"] <= 64, (name, r)
-        for name, lines in _kernel_bodies(asm, "k_block_chain2_t").items():
-            if "Li32E" not in name:
-                continue
-            code = [ln for ln in lines if ln and not ln.startswith((";", "."))]
-            scratch = [k for k, ln in enumerate(code) if ln.startswith("scratch_")]
-            assert all(k > 0.85 * len(code) for k in scratch), (name, scratch, len(code))
+            assert r["private_seg_size"] == 0, (name, r)
+        for name, lines in _kernel_functions(asm, "k_block_chain2_t").items():
+            blocks, cur = [], None
+            for ln in lines:
+                if ln.startswith(";;#ASMSTART"):
+                    cur = []
+                elif ln.startswith(";;#ASMEND"):
+                    if cur is not None:
+                        blocks.append(cur)
+                    cur = None
+                elif cur is not None and ln:
+                    cur.append(ln)
+            arith = ("v_fma_f64",) if fused else ("v_mul_f64", "v_add_f64")
+            ladders = [b for b in blocks if sum(1 for ln in b if ln.startswith(arith)) == (8 if fused else 16)]
+            assert len(ladders) >= 32, (name, len(ladders))    # 8 chunks x (straight | from a start index) x 2 phases
+            for b in ladders:
+                assert all(ln.startswith(arith + ("v_cmp_ge_i32", "s_mov_b64")) for ln in b), (name, b)
+            masked = [b for b in ladders if any(ln.startswith("v_cmp_ge_i32") for ln in b)]
+            assert masked and all(sum(1 for ln in b if ln.startswith("v_cmp_ge_i32")) == 8 and b[0] == "s_mov_b64 %s, exec" % b[0].split()[1].rstrip(",")
+                                  and b[-1].startswith("s_mov_b64 exec, ") for b in masked), name
 
 
 def _sweep_arith(asm, kernel):
