@@ -132,18 +132,22 @@ def loop_bound(ms_per_step, pivots_per_launch, avg_kernel_ms, info=None):
 
 def load_traffic(workload, world, block, kernel, fused=False):
     """PMC-measured HBM bytes per launch (profiles/*traffic_*.json, scripts/pmc_traffic.py) and where the figure comes
-    from — only when a file was measured for this workload, GPU count, pivots per sweep AND kernel (the fused-arithmetic
-    legs have files of their own, measured in that mode); otherwise (None, None): the number is a property of another run
-    (TCC counters cannot be read from inside bench.py)."""
-    names = ["traffic_%s_n%d.json" % (workload, world)]
-    if fused and world == 1:
-        names.insert(0, "r04_traffic_%s_fused_block%d.json" % (workload, int(block)))
+    from — only when a file was measured for this workload, GPU count, kernel AND arithmetic mode (a sweep launch moves the
+    tableau once whatever the number of pivots it applies, so the kernel decides, not the block size set on the handle);
+    otherwise (None, None): the number is a property of another run (TCC counters cannot be read from inside bench.py)."""
+    names = []
+    if world == 1 and fused:
+        names += ["r05_traffic_%s_block64.json" % workload, "r04_traffic_%s_fused_block%d.json" % (workload, int(block)),
+                  "r04_traffic_%s_fused_block32.json" % workload, "r04_traffic_%s_fused_block64.json" % workload]
+    if not fused:
+        names += ["traffic_%s_n%d.json" % (workload, world)]
     for name in names:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if int(t.get("pivots_per_sweep", -1)) == int(block) and t.get("kernel") == kernel:
+            if t.get("kernel") == kernel:
                 return t.get("hbm_bytes_per_launch"), {"file": "profiles/" + name, "kernel": t.get("kernel"),
                                                        "steps": t.get("steps"), "date": t.get("date"),
+                                                       "pivots_per_sweep": t.get("pivots_per_sweep"),
                                                        "note": "rocprofv3 --pmc passes of this command on another box"}
         except Exception:
             pass
@@ -413,6 +417,9 @@ def main():
         k, v = kv.split("=", 1)
         options[k] = int(v)
 
+    def single_path_extra(r):
+        return isinstance(r, dict) and r.get("extra_sampling_calls", 0) > 0
+
     def is_fused(inf):
         """the arithmetic a handle really computes in (lpx_state_info.arith_fused: LPX_OPT_FUSED resolved — by size unless
         the --option set says otherwise), which picks the oracle instantiation that replays it"""
@@ -441,20 +448,32 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         launches, kernel_ms = st.profile_read()
-        st.profile_enable(False)
         assert piv == Ks, "timed region did %d pivots instead of %d (status %d)" % (piv, Ks, status)
+        extra_calls = 0
+        if block > 1 and 0 < launches < 3 and args.event_every > 0:
+            # the roofline figure of a short command (the driver's 20 steps are ONE sweep launch) rests on at least three
+            # launches: the same budget again, outside the timed region, same kernel, same padding (Weak 8)
+            while launches < 3 and extra_calls < 4:
+                st.profile_enable(1)
+                status, piv2, _ = st.simplex_loop(max_pivots=Ks)
+                assert piv2 == Ks, "extra sampling call did %d pivots instead of %d (status %d)" % (piv2, Ks, status)
+                l2, k2 = st.profile_read()
+                launches, kernel_ms, extra_calls = launches + l2, kernel_ms + k2, extra_calls + 1
+        st.profile_enable(False)
         if block > 1:
             # blocked pivoting: blocks of `block` decisions while the budget lasts, the tail (incl. the decision that
             # only reports the end of the budget) in one last block; a block made of that decision alone has no sweep
             expect = 0 if args.event_every <= 0 else (Ks + block) // block if (Ks % block) else Ks // block
-            pivots_per_launch = Ks / float(launches) if launches else float("nan")
+            expect *= 1 + extra_calls
+            pivots_per_launch = Ks * (1 + extra_calls) / float(launches) if launches else float("nan")
         else:
             expect = 0 if args.event_every <= 0 else (Ks + args.event_every - 1) // args.event_every
             pivots_per_launch = 1.0
         assert launches == expect, "sampled %d row-update launches, expected %d" % (launches, expect)
         avg_ms = kernel_ms / launches if launches else float("nan")
         return {"st": st, "elapsed": elapsed, "block": block, "launches": launches, "avg_ms": avg_ms, "steps": Ks,
-                "warmup": Ws, "done": done + Ws + Ks, "pivots_per_launch": pivots_per_launch, "upload_s": t_up,
+                "warmup": Ws, "done": done + Ws + Ks * (1 + extra_calls), "pivots_per_launch": pivots_per_launch, "upload_s": t_up,
+                "extra_sampling_calls": extra_calls,
                 "info": st.info(), "fused": bool(st.info().get("arith_fused", 0))}
 
     def measured(r, mw, nw, name, Aw, bw, cw, with_parity):
@@ -733,7 +752,7 @@ def main():
                                world, ("blocked x%d" % block) if block > 1 else
                                ("plain" if args.no_lookahead else "look-ahead pipeline %d" % args.pipeline)))},
             "roofline": roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel_label(block, info), launches,
-                                       *load_traffic(args.workload, world, block, kernel_label(block, info)),
+                                       *load_traffic(args.workload, world, block, kernel_label(block, info), fused=is_fused(info)),
                                        fused=is_fused(info), clock_mhz=(info or {}).get("sweep_clock_mhz", 0),
                                        cus=(info or {}).get("sweep_cus", 0)),
             "loop_bound": loop_bound(1e3 * elapsed / K, pivots_per_launch, avg_ms, info),
@@ -741,6 +760,10 @@ def main():
             "host_gen_s": t_gen,
             "host_upload_s": t_up,   # hipMalloc + PCIe upload of this rank's tableau; outside the timed region
         }
+        if single_path_extra(r1_):
+            line["roofline"]["sampled_outside_timed_region"] = (
+                "%d further calls of the same %d-pivot budget behind the timed region (same kernel, same padding): the figure "
+                "rests on %d launches instead of one" % (r1_["extra_sampling_calls"], K, launches))
         if info is not None:   # what the engine actually did: grid of the decision kernel, its residency bound, CU masks
             line["engine"] = info
         if world > 1:
@@ -749,7 +772,8 @@ def main():
         if (peer or (world == 1 and not sharded)) and not args.no_parity:
             # the checker: the same LP replayed on the fp64 oracle for warm-up + steps pivots (outside the timed region)
             # (on the multi-GPU handle the bandwidth-bound leg has run behind the timed region: the replay covers it too)
-            line["parity_after_timed_region"] = parity_after(st, A, b, c, r1_.get("pivots_done", W + K) if peer else W + K,
+            # (a short command's extra sampling calls — roofline.launches_sampled >= 3 — have run on the handle too)
+            line["parity_after_timed_region"] = parity_after(st, A, b, c, r1_.get("pivots_done", W + K) if peer else r1_.get("done", W + K),
                                                              m, n, host_cores(), args.parity_max_pivots,
                                                              fused=is_fused(info))
         line["devices_visible"] = torch.cuda.device_count()
@@ -800,9 +824,9 @@ def main():
 
         want_fused = want_steady and not args.no_fused and "fused" not in options
         steady_fused = {}
-        done_total = W + K          # pivots the cfg4 handle has done (every leg below continues on it)
+        base_done = r1_.get("done", W + K) if single else W + K   # pivots the cfg4 handle has done (every leg below continues on it)
+        done_total = base_done
         if want_steady:
-            r1_["done"] = W + K
             # (its oracle replay comes after the one-pass legs, which continue on the same handle: one replay of everything)
             leg, done_total = steady_leg(r1_, A, b, c, m, n, "cfg4", False)
             if leg is not None:
@@ -837,7 +861,7 @@ def main():
             finally:
                 st.set_option("block", options.get("block", 0))
                 done_total = counted[0]
-        if single and not args.no_parity and done_total > W + K:
+        if single and not args.no_parity and done_total > base_done:
             # ONE replay of everything the cfg4 handle has done: headline, steady leg, one-pass legs (k_update_tiles<2> and
             # k_update at full height are checked here too)
             final = parity_after(st, A, b, c, done_total, m, n, host_cores(), args.parity_max_pivots,

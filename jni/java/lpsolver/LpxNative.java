@@ -15,9 +15,11 @@ final class LpxNative {
 
   private LpxNative() {}
 
-  /** Arithmetic of every handle created afterwards (lpx.h LPX_OPT_FUSED / lpx_solve_options.fused): false (default) =
-   *  product and difference of every update rounded separately, as the reference's BigDecimal code rounds them
-   *  (LPState.java:162); true = fused multiply-add updates (one binary rounding; faster sweeps, same tolerance class). */
+  /** Arithmetic of every handle created afterwards (lpx.h LPX_OPT_FUSED / lpx_solve_options.fused).  Never called: the
+   *  library chooses by size (fused multiply-add updates from 0.5 GiB of tableau, where they are 5-75 % faster; both binary
+   *  modes leave the BigDecimal pivot sequence equally often, tests/golden/divergence_census.json).  true = fused everywhere;
+   *  false = product and difference of every update rounded separately, as the reference's BigDecimal code rounds them
+   *  (LPState.java:162): the opt-out. */
   static native void setFusedArithmetic(boolean on);
 
   /** lpx_solve — replaces LPSolver.solve(LPStandardForm) (LPSolver.java:78).

@@ -9,12 +9,13 @@
 
 #define NAME(fn) Java_lpsolver_LpxNative_##fn
 
-/* Arithmetic of the handles this shim creates (LpxNative.setFusedArithmetic): 0 = product and difference of every
- * update rounded separately, as the reference rounds them (default); 1 = fused multiply-add updates (LPX_OPT_FUSED). */
+/* Arithmetic of the handles this shim creates (LpxNative.setFusedArithmetic), as lpx_solve_options.fused takes it: 0 (never
+ * called) = the library's choice by size (LPX_OPT_FUSED = 2: fused multiply-add updates from 0.5 GiB of tableau); 1 = fused
+ * everywhere; -1 = product and difference of every update rounded separately, as the reference rounds them (the opt-out). */
 static int g_fused = 0;
 JNIEXPORT void JNICALL NAME(setFusedArithmetic)(JNIEnv* env, jclass cls, jboolean on) {
   (void)env; (void)cls;
-  g_fused = on ? 1 : 0;
+  g_fused = on ? 1 : -1;
 }
 
 static double* get_d(JNIEnv* env, jdoubleArray a) { return a ? (*env)->GetDoubleArrayElements(env, a, NULL) : NULL; }
@@ -92,7 +93,7 @@ JNIEXPORT jlong JNICALL NAME(stateCreate)(JNIEnv* env, jclass cls, jint m, jint 
   jint* perm = get_i(env, jperm);
   lpx_state* s = NULL;
   int rc = lpx_state_create(m, n, a, n, b, c, v, (const int32_t*)perm, 0, m, 0, &s);
-  if (rc == 0 && g_fused) rc = lpx_state_set_option(s, LPX_OPT_FUSED, 1);
+  if (rc == 0 && g_fused) rc = lpx_state_set_option(s, LPX_OPT_FUSED, g_fused > 0 ? 1 : 0);
   put_d(env, ja, a, JNI_ABORT); put_d(env, jb, b, JNI_ABORT); put_d(env, jc, c, JNI_ABORT);
   put_i(env, jperm, perm, JNI_ABORT);
   return rc == 0 ? (jlong)(intptr_t)s : 0;

@@ -34,14 +34,15 @@ def test_roofline_block_is_bounded_and_names_the_binding_term():
 
 
 def test_traffic_files_match_their_kernel_and_mode():
-    """roofline.traffic is quoted only from a counter file of the same workload, block size, kernel — and, for the
-    fused legs, the file measured in that mode."""
+    """roofline.traffic is quoted only from a counter file of the same workload, kernel and arithmetic mode."""
     t, src = bench.load_traffic("cfg4", 1, 64, "k_sweep64_mfma2", fused=True)
-    assert t and src["file"].endswith("r04_traffic_cfg4_fused_block64.json") and 1.0 < t / (16.0 * 32768 * 16384) < 1.06
+    assert t and "k_sweep64_mfma2" == src["kernel"] and 1.0 < t / (16.0 * 32768 * 16384) < 1.06
     assert bench.load_traffic("cfg4", 1, 64, "k_sweep64_mfma2", fused=False) == (None, None)
-    assert bench.load_traffic("cfg4", 1, 32, "k_sweep64_mfma2", fused=True) == (None, None)
-    t32, src32 = bench.load_traffic("cfg4", 1, 32, "k_sweep32_pull", fused=True)
-    assert t32 and src32["file"].endswith("fused_block32.json")
+    # the driver's 20-pivot command in the by-size arithmetic: the handle's block size is 64, the kernel that ran is the
+    # sweep of blocks of up to 32 in the fused mode
+    t32, src32 = bench.load_traffic("cfg4", 1, 64, "k_sweep32_pull", fused=True)
+    assert t32 and src32["file"].endswith("fused_block32.json") and src32["kernel"] == "k_sweep32_pull"
+    assert bench.load_traffic("cfg4", 1, 32, "k_sweep64_one", fused=True) == (None, None)
 
 
 def test_loop_bound_names_the_slower_half():
