@@ -1088,6 +1088,28 @@ def test_blocked_loop_many_blocks_and_dantzig(lps, oracle):
         st.close()
 
 
+@pytest.mark.parametrize("shape", [(600, 900), (1536, 700)])
+def test_blocks_of_64_with_long_ladders(lps, oracle, shape):
+    """Dantzig pricing seldom returns to a slot, so hardly any decision restarts inside the pending pivots: with blocks of
+    64 in the overlapped loop a decision's ladder then runs through up to 128 pending pivots — more than the one window of
+    eight live chunks a thread of k_block_chain2_t<64, ...> holds in registers: the second window (a second round trip) and
+    the boundary value between the two blocks' pivots in either window.  Both rules, budgets that are no multiples of 64."""
+    m, n = shape
+    A, b, c = dense_lp(m, n, seed=m + 7 * n)
+    for pricing, rule in (("dantzig", 1), (None, 0)):
+        st = lps.LPState(A, b, c, block=64, **({"pricing": pricing} if pricing else {}))
+        ref = oracle.State(A, b, c, kind=oracle.FP64, pricing=rule)
+        for budget in (200, 333, 129):
+            status, pivots, _ = st.simplex_loop(max_pivots=budget)
+            want = ref.simplex_loop(max_pivots=budget)
+            assert (status, pivots) == (want["status"], want["pivots"]), (pricing, budget)
+            assert_state_bits_equal(st.read(), ref.read(), "%s budget %d of %s" % (pricing, budget, shape))
+            if status != 9:
+                break
+        assert st.info()["block"] == 64
+        st.close()
+
+
 def test_blocked_pivoting_degenerate_unbounded_and_tracking(lps, oracle):
     # ties everywhere
     m, n = 70, 40

@@ -19,6 +19,9 @@ def _run(script, *args):
 @pytest.mark.parametrize("summary,kernel,csvs", [
     ("r05_pmc_summary_k_sweep64_mfma2.txt", "k_sweep64_mfma2",
      ["profiles/r05_pmc/pmc1_k_sweep64_mfma2.csv", "profiles/r05_pmc/pmc2_k_sweep64_mfma2.csv"]),
+    ("r04_pmc_summary_fused_k_sweep64_mfma2.txt", "k_sweep64_mfma2",
+     ["profiles/r04_pmc/pmc1_f64.csv", "profiles/r04_pmc/pmc2_f64.csv"]),   # (round 4 tracked CSVs of another run: replaced)
+    ("r04_pmc_summary_fused_k_sweep32_pull.txt", "k_sweep32_pull", ["profiles/r04_pmc/pmc1_f32.csv"]),
     ("r03_sweep_cfg4_pmc_summary.txt", None, None),
 ])
 def test_counter_summaries_reproduce(summary, kernel, csvs):
