@@ -30,8 +30,7 @@ def main():
     max_lp_pivots = int(sys.argv[3]) if len(sys.argv) > 3 else -1   # stop an LP after about this many pivots (big shapes)
     fused = len(sys.argv) > 4 and sys.argv[4] == "fused"
     kind = oracle.FP64_FUSED if fused else oracle.FP64
-    if fused:
-        lps.set_default_arithmetic("fused")
+    lps.set_default_arithmetic("fused" if fused else "plain")   # (explicit: the library's own default is by size)
     n_lp = n_cmp = pivots_total = 0
     while time.time() < t_end:
         m, n = shapes[n_lp % len(shapes)]

@@ -1,5 +1,5 @@
 """Soak test of lpx_multi with every "device" = device 0 (row-block shards exchanging candidates and pivot rows through
-the peer mailboxes of k_block_chain_t<true>): random LPs solved in random budget pieces by 2-4 shards, both host loops
+the peer mailboxes of k_block_chain2_t<..., MG = true>): random LPs solved in random budget pieces by 2-4 shards, both host loops
 (decisions beside the sweeps / serial), every intermediate state compared bit for bit with the fp64 oracle.
     GPU_MAX_HW_QUEUES=16 python scripts/soak_multi.py [seconds=120]"""
 import os
@@ -23,6 +23,7 @@ def main():
     budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     t_end = time.time() + budget_s
     rng = np.random.default_rng(20261004)
+    lps.set_default_arithmetic("plain")   # (explicit: checked against the fp64 oracle)
     shapes = [(300, 700), (700, 1100), (1100, 260), (64, 2100), (513, 515)]
     n_lp = n_cmp = pivots_total = 0
     while time.time() < t_end:
