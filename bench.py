@@ -629,8 +629,11 @@ def main():
                 p2 = s1.simplex_loop(max_pivots=max(8, args.onepass_steps // 2))[1]
                 dt2 = time.perf_counter() - t1
                 ref_1gpu = {"blocked": p1 / dt1, "one_pass_per_pivot": p2 / dt2, "unit": "pivots/s",
-                            "what": "the same tableau on GPU %d alone in this run: %d pivots after %d warm-up (default loop), "
-                                    "then %d pivots with one pass per pivot" % (devices[0], p1, W, p2)}
+                            "arith_fused": int(s1.info().get("arith_fused", 0)),
+                            "what": "the same tableau on GPU %d alone in this run: %d pivots after %d warm-up (default loop: the "
+                                    "one-device handle chooses its arithmetic by size — arith_fused — while shards keep the two "
+                                    "roundings per update unless --option fused=1), then %d pivots with one pass per pivot"
+                                    % (devices[0], p1, W, p2)}
             except Exception as ex:   # noqa: BLE001
                 ref_1gpu = {"error": "%s: %s" % (type(ex).__name__, ex)}
             finally:

@@ -138,7 +138,7 @@ typedef enum lpx_option {
   LPX_OPT_UPDATE_U = 11,      /* one-pass update: 16-byte accesses per thread per row (1, 2, 4)                      */
   LPX_OPT_UPDATE_ROWS = 12,   /* one-pass update: rows per workgroup (even, 2..256)                                  */
   LPX_OPT_A2_OFFSET = 13,     /* skew between the two tableau buffers in doubles (before the second one exists)      */
-  LPX_OPT_SWEEP_FORM = 14,    /* blocks of 17..32: 0 = k_sweep32_pull (LDS-DMA staging, batches pulled in address order; default), 1 = k_sweep32_steady (register staging, runs of rows), 2 = k_sweep32_dma (LDS-DMA, runs).  Blocks of 33..64: 0 = k_sweep64_one (round 4: one wave per 64-column sub-strip; default), 1 = k_sweep64_pipe (full blocks of 64 only), 2 = k_sweep64_pull (round 3: a pair of waves per 128-column sub-strip); in the fused-arithmetic mode with 16-row tiles (m % 16 == 0) 0 = k_sweep64_mfma2 (the matrix cores, two waves per SIMD), 4 = k_sweep64_mfma (one wave per SIMD), 3 = k_sweep64_one */
+  LPX_OPT_SWEEP_FORM = 14,    /* 0 (default) = the sweep kernels of the library: blocks of 17..32 k_sweep32_pull (LDS-DMA staging, batches pulled in address order); blocks of 33..64 k_sweep64_one (one wave per 64-column sub-strip), in the fused-arithmetic mode with 16-row tiles (m % 16 == 0) k_sweep64_mfma2 (the matrix cores); 3 = k_sweep64_one in the fused mode too.  1, 2, 4 name the superseded kernels of csrc/variants/ (k_sweep32_steady / k_sweep64_pipe, k_sweep32_dma / k_sweep64_pull, k_sweep64_mfma): they select them in the variants library (make variants) only and mean the default here */
   LPX_OPT_MULTI_ONEHOP = 15,  /* lpx_multi: 1 = every shard ships its candidate's row with its candidate (one cross-device hop per decision instead of two); 0 (default) = candidates, then the winner's normalised row */
   LPX_OPT_SWEEP_CUS = 16,     /* overlapped loop: CUs of the sweep stream's mask (multiple of 8; 0 = all but the decisions'); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
   LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16; other values are rounded down to a multiple of 4 but never below 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
