@@ -2865,36 +2865,6 @@ static_assert(2 * kDmaLdsBytes <= 160 * 1024, "two workgroups per CU");
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)(p);
 }
-// One batch: RB = 4 rows of this wave's 1 KiB each -> LDS at lds, lds + 1 KiB, ...  The leading lgkmcnt(0) retires the
-// wave's own ds_reads of the slot being refilled (M0, the LDS base of an LDS-DMA, is written in the statement that uses
-// it and restored: the compiler reserves it).
-template <bool NT>
-__device__ __forceinline__ void dma_batch4(const char* base, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
-                                           uint32_t lds) {
-  unsigned keep;
-  if (NT)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %3, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %4, %1 nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %5, %1 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds) : "memory", "scc");
-  else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %3, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %4, %1\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %5, %1\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(base), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(lds) : "memory", "scc");
-}
-// two 1 KiB pieces from per-lane addresses (the multipliers: L2-resident, default cache policy)
-__device__ __forceinline__ void dma_pieces2(const double* p0, const double* p1, uint32_t lds) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(p0), "v"(p1), "s"(lds) : "memory", "scc");
-}
 template <int N>
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
