@@ -815,6 +815,10 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
   int64_t decided = 0;
   int nb_prev = 0, nblk = 0;
   const bool serial = s->opt[LPX_OPT_OVERLAP_SERIAL] != 0;
+  // (The decision kernel's private ring copies — identity padding behind a block's last pivot, its start indices — are
+  // only meaningful to the kernel FORM that wrote them.  A launch treats the other ring half as pending pivots only for
+  // k > 0 of THIS call (n_old = 0 for the first block of every call), and the form is read once per launch from the
+  // handle, which no option call can reach while this function runs: the two forms never meet inside one loop.)
   auto issue_block = [&](int k) -> int {  // 1: the budget is spent, nothing issued
     const int nb = block_len(K, max_pivots, decided);
     if (nb <= 0) return 1;

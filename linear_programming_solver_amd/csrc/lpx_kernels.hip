@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
   }
 }
 
-// ---- k_block_chain2: the same decisions on a shorter critical path (one device; option chain_form = 1) --------------
+// ---- k_block_chain2: the same decisions on a shorter critical path (one device and shards; option chain_form = 1) ----
 // k_block_chain_t spends a decision in ~8 dependent memory round trips and ~3 000 instructions that a lone wave per SIMD
 // executes one after the other (13-14 us alone, 18-20 us beside a sweep, whatever it computes).  What is not a data
 // dependency of the algorithm is taken off that path here:
@@ -1588,9 +1588,12 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
 //                newer: a candidate record of decision s+1 implies col_s is visible, a hand-off record of decision s+1
 //                implies prow_s and c of decision s are.  The stale copies kept for the fix-up (col0, row0) are plain
 //                stores: only the next kernel reads them.
-//   instructions wave minima by DPP butterflies + four v_readlane instead of six rounds of LDS shuffles; the pending
+//   instructions wave minima by DPP butterflies + four v_readlane instead of six rounds of LDS shuffles, ONE workgroup meeting
+//                per minimum (rr_block_min_rec), the workgroups' candidates reduced by every wave for itself; the pending
 //                pivots' parameters come from LDS one chunk of eight AHEAD of the arithmetic that uses them, as 16-byte
-//                reads; a chunk whose eight steps are all live carries no per-step predicate.
+//                reads; the pending pivots themselves are a ladder without branches or selects (chain8 / chain8_from, round
+//                5): a thread's chain STARTS behind the last pending pivot that replaced its value, one window of live
+//                chunks in registers.
 //   workgroup 0  (the one everybody waits for) only does what the hand-off needs: the loop state (v, perm, the ring's
 //                parameter block, the host's snapshot) is kept by the LAST workgroup's first thread, the candidates for
 //                the rare full exchange are reduced only when that exchange happens, and the column a later restart
@@ -1598,8 +1601,9 @@ __global__ __launch_bounds__(256) void k_block_chain_t(const ChainArgs P) {
 // When workgroup 0 finds no entering slot in its window (2 % of the decisions; always under Dantzig pricing or with
 // fewer than 256 columns) the decision ends as in k_block_chain_t: drain, grid barrier, every workgroup reduces the
 // candidates, and the next phase A loads c[e] and prow_s[e] from memory.
-// Arithmetic, ownership, restart logic, ring layout and the bounded spins are those of k_block_chain_t (own_dvc is not
-// used); the kernels must not take turns INSIDE one loop (the private ring copies differ in that), between loops they may.
+// Arithmetic, ownership, ring layout and the bounded spins are those of k_block_chain_t (own_dvc is not used; the start
+// indices own_rs_a / own_rs_b are this kernel's own); the kernels must not take turns INSIDE one loop (the private ring
+// copies differ in that — lpx_engine.cpp blocked_loop_overlapped says why they cannot), between loops they may.
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
 template <int CTRL>
