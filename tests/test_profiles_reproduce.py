@@ -19,6 +19,8 @@ def _run(script, *args):
 @pytest.mark.parametrize("summary,kernel,csvs", [
     ("r05_pmc_summary_k_sweep64_mfma2.txt", "k_sweep64_mfma2",
      ["profiles/r05_pmc/pmc1_k_sweep64_mfma2.csv", "profiles/r05_pmc/pmc2_k_sweep64_mfma2.csv"]),
+    ("r05_pmc_summary_decisions_alone_cfg3.txt", "k_block_chain2_t",
+     ["profiles/r05_pmc/decision_pmc_a.csv", "profiles/r05_pmc/decision_pmc_b.csv"]),
     ("r04_pmc_summary_fused_k_sweep64_mfma2.txt", "k_sweep64_mfma2",
      ["profiles/r04_pmc/pmc1_f64.csv", "profiles/r04_pmc/pmc2_f64.csv"]),   # (round 4 tracked CSVs of another run: replaced)
     ("r04_pmc_summary_fused_k_sweep32_pull.txt", "k_sweep32_pull", ["profiles/r04_pmc/pmc1_f32.csv"]),
