@@ -17,7 +17,7 @@ PRICING = {"reference": 0, "first-positive": 0, "dantzig": 1, 0: 0, 1: 1}
 OPTIONS = {"block": 0, "chain": 1, "overlap": 2, "overlap_serial": 3, "overlap_mask": 4, "chain_wgs": 5,
            "chain_fences": 6, "sweep_rows": 7, "nt": 8, "batch": 9, "chain_trace": 10, "update_u": 11,
            "update_rows": 12, "a2_offset": 13, "sweep_form": 14, "multi_onehop": 15, "sweep_cus": 16, "chain_cus": 17,
-           "fused": 18, "chain_form": 19}
+           "fused": 18, "chain_form": 19, "fixup_side": 20}
 
 # Arithmetic of the handles the host classes create when the caller does not say (option "fused" / LPSolver(fused=...)):
 # None = the library's choice (LPX_OPT_FUSED = 2: by size — fused multiply-add updates on an unsharded tableau of 0.5 GiB

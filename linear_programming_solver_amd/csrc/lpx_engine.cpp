@@ -80,6 +80,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_CHAIN_CUS", 0, 0, 16},            // LPX_OPT_CHAIN_CUS
     {"LPX_FUSED", 2, 0, 2},                 // LPX_OPT_FUSED
     {"LPX_CHAIN_FORM", 1, 0, 1},            // LPX_OPT_CHAIN_FORM
+    {"LPX_FIXUP_SIDE", 2, 0, 3},            // LPX_OPT_FIXUP_SIDE
 };
 
 static const int64_t* env_defaults() {
@@ -183,6 +184,8 @@ static void free_block_ring(lpx_state* s) {
   (void)hipFree(s->R.tickets);
   (void)hipFree(s->R.clk);
   (void)hipFree(s->R.col_packed);
+  (void)hipFree(s->R.fix_col);
+  (void)hipFree(s->R.fix_row);
   (void)hipFree(s->R.mg_mail);
   (void)hipFree(s->R.mg_arrive);
   (void)hipFree(s->R.mg_candrow);
@@ -224,6 +227,8 @@ void free_state(lpx_state* s) {
   for (hipEvent_t e : s->ev_ov_chain) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_ov_sweep) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : s->ev_ov_join) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t t : s->ov_fix) if (t) (void)hipStreamDestroy(t);
+  for (hipEvent_t e : s->ev_ov_fix) if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -665,7 +670,7 @@ int device_cus(const lpx_state* s) {
 
 // B / R: destination buffers and the ring half of the block; A_src / b_src != NULL: out of place
 int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers& B, const lpxk::BlockRing& R,
-                                 const double* A_src, const double* b_src) {
+                                 const double* A_src, const double* b_src, const lpxk::FixSide* side) {
   const bool sample = s->prof > 0 && (s->prof_seq++ % s->prof) == 0;
   if (sample) {
     if (s->ev_used + 2 > s->ev.size()) {
@@ -684,14 +689,14 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
   s->info.sweep_rows = lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, (int)s->opt[LPX_OPT_SWEEP_ROWS],
                                                 s->nontemporal, stream, A_src, b_src,
                                                 sample ? s->ev[s->ev_used + 1] : nullptr, cus,
-                                                (int)s->opt[LPX_OPT_SWEEP_FORM], &kernel_used);
+                                                (int)s->opt[LPX_OPT_SWEEP_FORM], &kernel_used, side);
   s->info.sweep_kernel = kernel_used;
   if (sample) s->ev_used += 2;
   HIP_TRY(hipGetLastError());
   return 0;
 }
 static int launch_sweep_profiled(lpx_state* s, int K) {
-  return launch_sweep_profiled(s, K, s->stream, s->B, s->R, nullptr, nullptr);
+  return launch_sweep_profiled(s, K, s->stream, s->B, s->R, nullptr, nullptr, nullptr);
 }
 
 // Ring half h as a ring of its own (what the sweep / fix-up kernels take).
@@ -702,6 +707,8 @@ lpxk::BlockRing ring_half(const lpx_state* s, int h) {
   R.row0 += o * s->B.ld;
   R.col += o * R.mp;
   R.col0 += o * R.mp;
+  if (R.fix_col) R.fix_col += o * R.mp;
+  if (R.fix_row) R.fix_row += o * s->B.ld;
   R.up += o;
   return R;
 }
@@ -775,6 +782,41 @@ int ensure_overlap_streams(lpx_state* s) {
   return 0;
 }
 
+// The fix-up of block k beside sweep k (LPX_OPT_FIXUP_SIDE): its chains read ring values only, so they need not wait for
+// the sweep — only their copy into the tableau does.  mode 1: a stream with the sweep's CU mask, 2 (default): the
+// decisions' CUs, 3: no mask.  Measured at cfg4 (profiles/r05_fixup_beside_the_sweep.txt): behind the sweep the fix-up
+// takes 76-95 us of every 2.05 ms block, its copy kernel 19-23; the chains themselves take 120-150 us on the decisions'
+// 64 CUs (which have 0.8 ms of every block to spare there) and 700-800 us squeezed in between the sweep's own waves.
+int ensure_fix_side(lpx_state* s, int mode) {
+  if (mode < 1 || mode > 3) return fail(LPX_BAD_ARGUMENT, "ensure_fix_side: mode");
+  if (!s->R.fix_col) {
+    const size_t K = 2 * lpxk::kBlockMax;
+    HIP_TRY(hipMalloc((void**)&s->R.fix_col, K * (size_t)s->R.mp * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&s->R.fix_row, K * (size_t)s->B.ld * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(s->R.fix_col, 0, K * (size_t)s->R.mp * sizeof(double), s->stream));
+    HIP_TRY(hipMemsetAsync(s->R.fix_row, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
+  }
+  for (int k = 0; k < 2; k++)
+    if (!s->ev_ov_fix[k]) HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_fix[k], hipEventDisableTiming));
+  if (s->ov_fix[mode]) return 0;
+  bool made = false;
+  if (s->ov_masked && mode != 3) {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+    const int ncu = prop.multiProcessorCount, per_xcd = ncu / 8;
+    const int chain_per_xcd = s->ov_chain_cus / 8, sweep_per_xcd = s->ov_sweep_cus / 8;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int cu = 0; cu < ncu; cu++) {
+      const bool chain_cu = cu / 8 >= per_xcd - chain_per_xcd, sweep_cu = !chain_cu && cu / 8 < sweep_per_xcd;
+      if (mode == 1 ? sweep_cu : chain_cu) mask[cu / 32] |= 1u << (cu % 32);
+    }
+    made = hipExtStreamCreateWithCUMask(&s->ov_fix[mode], (uint32_t)mask.size(), mask.data()) == hipSuccess;
+    if (!made) { (void)hipGetLastError(); s->ov_fix[mode] = nullptr; }
+  }
+  if (!made) HIP_TRY(hipStreamCreateWithFlags(&s->ov_fix[mode], hipStreamNonBlocking));
+  return 0;
+}
+
 // The blocked loop with the decisions one block ahead of the sweeps.  Block k's decisions (k_block_chain) read
 // the tableau as it was BEFORE block k-1's sweep and see that block's pivots as pending ones, like their own; so
 // sweep k-1 (out of place, buffer (k-1)&1 -> k&1) and decisions k run side by side, on disjoint XCDs:
@@ -815,6 +857,8 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
   int64_t decided = 0;
   int nb_prev = 0, nblk = 0;
   const bool serial = s->opt[LPX_OPT_OVERLAP_SERIAL] != 0;
+  const int fix_mode = serial ? 0 : (int)s->opt[LPX_OPT_FIXUP_SIDE];
+  if (fix_mode > 0) if (int rc = ensure_fix_side(s, fix_mode)) return rc;
   // (The decision kernel's private ring copies — identity padding behind a block's last pivot, its start indices — are
   // only meaningful to the kernel FORM that wrote them.  A launch treats the other ring half as pending pivots only for
   // k > 0 of THIS call (n_old = 0 for the first block of every call), and the form is read once per launch from the
@@ -848,7 +892,11 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
     Buffers Bdst = s->B;
     Bdst.A = Abuf[h ^ 1];
     Bdst.b = bbuf[h ^ 1];
-    if (int rc = launch_sweep_profiled(s, nb, s->ov_sweep, Bdst, ring_half(s, h), Abuf[h], bbuf[h])) return rc;
+    // (the side stream: chains k start when decisions k are through — their ring half and their image half are free by
+    // then: chain k itself waited for sweep k-2, which ends with the copy of those images —, and run in stream order, so
+    // the b they read is the one chains k-1 wrote)
+    const lpxk::FixSide side{fix_mode > 0 ? s->ov_fix[fix_mode] : nullptr, s->ev_ov_chain[h], s->ev_ov_fix[h]};
+    if (int rc = launch_sweep_profiled(s, nb, s->ov_sweep, Bdst, ring_half(s, h), Abuf[h], bbuf[h], fix_mode > 0 ? &side : nullptr)) return rc;
     HIP_TRY(hipEventRecord(s->ev_ov_sweep[h], s->ov_sweep));
     decided += nb;
     nb_prev = nb;
@@ -912,6 +960,9 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
   s->info.overlapped = 0;
   LpxCtl* d_snap = nullptr;  // the pinned snapshots as the device sees them
   if (fused) HIP_TRY(hipHostGetDevicePointer((void**)&d_snap, s->h_snap, 0));
+  // (the fix-up stays BEHIND the sweep here: beside it — in place that is just as valid, its chains read ring values only —
+  // the sweep, which has the whole chip and is bound by HBM in this form, lost more than the fix-up takes: the driver's
+  // 20-pivot command at cfg4 1.515 -> 1.59 ms per sweep, 10.5k -> 10.2k pivots/s, profiles/r05_fixup_beside_the_sweep.txt)
   auto issue_block = [&](int slot) -> int {
     const int nb = block_len(K, max_pivots, decided);
     if (fused && nb > 0) {

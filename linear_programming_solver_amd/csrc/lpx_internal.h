@@ -58,6 +58,9 @@ struct lpx_state {
   int ov_chain_cus = 0;             // CUs the chain stream may use
   int ov_sweep_cus = 0;           // CUs of the sweep stream's mask (LPX_OPT_SWEEP_CUS)
   hipEvent_t ev_ov_chain[2] = {nullptr, nullptr}, ev_ov_sweep[2] = {nullptr, nullptr}, ev_ov_join[3] = {nullptr, nullptr, nullptr};
+  // the fix-up's chains beside the sweep (LPX_OPT_FIXUP_SIDE = 1..3: on the sweep's CUs, the decisions' CUs, all CUs)
+  hipStream_t ov_fix[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_ov_fix[2] = {nullptr, nullptr};     // chains of block k done (the copy kernel waits for it)
   double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
   LpxCtl* h_snap = nullptr;         // 2 pinned snapshots for the batched loop (batch k+1 in flight while k is read)
@@ -107,7 +110,8 @@ int block_len(int K, int64_t max_pivots, int64_t decided);
 int clamp_chain_wgs(lpx_state* s, int want, int cus);
 int device_cus(const lpx_state* s);
 int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers& B, const lpxk::BlockRing& R,
-                          const double* A_src, const double* b_src);
+                          const double* A_src, const double* b_src, const lpxk::FixSide* side = nullptr);
+int ensure_fix_side(lpx_state* s, int mode);   // ov_fix[mode], ev_ov_fix and the ring's images (R.fix_col / R.fix_row)
 lpxk::BlockRing ring_half(const lpx_state* s, int h);
 void launch_seed_entering(lpx_state* s);
 int launch_update_profiled(lpx_state* s, const double* prow = nullptr, const LpxCtl* up = nullptr,

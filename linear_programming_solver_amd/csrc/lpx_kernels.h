@@ -81,6 +81,8 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   int32_t* chain_own_rs;   // mp + ld: k_block_chain2's start indices per row / per slot (last pending pivot that replaced it)
   long long* chain_dbg;    // diagnostics (LPX_OPT_CHAIN_TRACE): 5 timestamps per decision of the last block
   unsigned* census;        // [w] = XCC id + 1 of chain workgroup w; [kChainMaxWgs] = OR of (1 << XCC id) of sampled sweep workgroups
+  double* fix_col;         // overlapped loop: images of the fix-up's entering columns [chain][mp] (NULL: the fix-up follows the sweep and writes the tableau itself)
+  double* fix_row;         // ... and of its pivot rows [chain][ld]; both 2 x kBlockMax chains like the rings
   double* col_packed;      // k_sweep32_pull: the block's multipliers as [batch of 4 rows][pivot][row]: (mp / 4) x 1 KiB (2 KiB for blocks of 64)
   unsigned* tickets;       // k_sweep32_pull: one batch counter per 128-column sub-strip, 128 bytes apart (ld / 128 of them)
   long long* clk;          // clock probe of the last pulled sweep, per XCD x: clk[4 x + 0..1] = {s_memtime, 100 MHz} in front of it, [4 x + 2..3] behind it
@@ -107,6 +109,8 @@ struct MgPeers {
 };
 // which kernel swept the bulk of the tableau (lpx_state_info.sweep_kernel)
 enum SweepKernel { kSweepNone = 0, kSweepTiles = 1, kSweepMulti = 2, kSweepSteady = 3, kSweepPipe64 = 4, kSweepDma = 5, kSweepPull = 6, kSweepPull64 = 7, kSweepOne64 = 8, kSweepMfma64 = 9, kSweepMfma642 = 10 };
+// The fix-up of a block beside its sweep (launch_block_sweep): where its chains run and the two events that tie them in.
+struct FixSide { hipStream_t stream; hipEvent_t ready, done; };
 struct RestoreEntry { int32_t is_basic; int32_t index; double k; };  // index = row r (basic) or post-drop slot
 
 // ---- launch wrappers --------------------------------------------------------------------------------------------

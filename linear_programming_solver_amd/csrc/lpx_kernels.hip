@@ -1749,7 +1749,6 @@ __global__ __launch_bounds__(NT) void k_block_chain2_t(const ChainArgs P) {
   __shared__ unsigned sh_part[kChainMaxWgs * 8], sh_hand[8];
   __shared__ __attribute__((aligned(16))) double sh_pe[2 * KB], sh_cs[2 * KB], sh_dv[2 * KB], sh_p[2 * KB], sh_bl[2 * KB];
   __shared__ __attribute__((aligned(16))) int sh_e[2 * KB], sh_l[2 * KB];
-  __shared__ double sh_win[2];
   __shared__ int sh_fail;
 #ifdef LPX_CHAIN2_FINE   // diagnostic build: 16 stamps per decision (slots 8..15: inside the phases)
 #define LPX_C2_STAMP(k) if (P.dbg && lead) P.dbg[s * 16 + (k)] = wall_clock64();
@@ -3380,14 +3379,17 @@ __global__ __launch_bounds__(256, 2) void k_sweep64_mfma2(double* A, const doubl
                                                           const double* __restrict__ prow_ring,
                                                           const LpxCtl* __restrict__ ring, int kmax, int nstrips_full,
                                                           const double* colM,   // [tile][group][lane]
-                                                          unsigned* tickets) {
+                                                          unsigned* tickets, int kmin) {
   constexpr int NG = 16, CT = 4;
   constexpr int kRsrcWord3 = 0x00020000;           // raw buffer, 32-bit data format (gfx9 family)
   constexpr int kAuxNt = NT ? 2 : 0;               // cache policy bit 1 = nt
   __shared__ __attribute__((aligned(16))) double sh_b[2 * NG * CT * 64];
   __shared__ int sh_np;
   const int np = ring_count(ring, 64, kmax, &sh_np);
-  if (np <= 32) return;
+  // kmin = 33: a block of at most 32 valid pivots (it ended early) is left to the generic kernels launched behind; kmin = 1
+  // (whole strips only, no such launches): taken here too — the identity steps of a partly filled block are exact
+  // (multiplier -0.0 against a pivot-row value of +0.0), whatever their number
+  if (np < kmin) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int ngroups = nstrips_full * 4;            // groups of 128 columns
@@ -3552,13 +3554,30 @@ __device__ __forceinline__ double apply_pivot(double v, int i, int j, int l_r, i
 //     __ballot per wave (lane r asks for pivot r), then a scalar bit test per r.
 // A step without either is eight multiply-adds on eight LDS values; with one, the old selects behind a uniform branch.
 constexpr int kFixChunk = 8;
+// The chains of a job: the LAST pending pivot of every distinct key (entering slot / leaving row), in pivot order.  Called
+// by the first wave of a workgroup (all 64 lanes) between two barriers; keys[q] = -1 behind the last pivot.
+__device__ __forceinline__ void fix_pick_chains(const int* keys, int np, int* sh_pick, int* sh_npick) {
+  const int q = threadIdx.x;
+  const int key = keys[q];
+  bool keep = q < np;
+  for (int r = q + 1; r < np; ++r) keep = keep && keys[r] != key;
+  const unsigned long long mask = __ballot(keep);
+  if (keep) sh_pick[__popcll(mask & ((1ull << q) - 1ull))] = q;
+  const int npick = __popcll(mask);
+  if (q < kFixChunk) sh_pick[npick + q] = 0;   // (padding of the last chunk: reads stay inside the ring)
+  if (q == 0) *sh_npick = npick;
+}
 __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int64_t ld, int n, int m_local, int row0,
                                                      double* b, const double* __restrict__ prow_ring,
                                                      const double* __restrict__ col_ring,
                                                      const double* __restrict__ col0_ring,
                                                      const double* __restrict__ row0_ring, int64_t mp,
                                                      const LpxCtl* __restrict__ ring, int kmax,
-                                                     const double* b_src, long long* __restrict__ clk) {
+                                                     const double* b_src, long long* __restrict__ clk,
+                                                     double* __restrict__ img_col, double* __restrict__ img_row) {
+  // img_col / img_row != NULL (the overlapped loop): the chains are computed BESIDE the block's sweep, from ring values
+  // only, into compact images [chain][row] / [chain][column]; k_block_fixup_scatter copies them into the tableau once the
+  // sweep is through.  b (job 2) is written in place either way: the sweep does not touch it.
   static_assert(kBlockMax <= 64, "one lane per pending pivot in the hit ballots");
   if (clk && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
     const unsigned x = xcc_id() & 7u;
@@ -3587,17 +3606,7 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
   // LAST pivot of every slot (row) is a chain here — under the first-positive rule a block of 64 pivots touches 10-15
   // distinct slots and rows (three decisions of four come back to a slot of the last 48), i.e. a quarter of the chains
   // and of the scattered column writes.
-  if (job != 2 && threadIdx.x < 64) {
-    const int q = threadIdx.x;
-    const int key = job == 1 ? sh_l[q] : sh_e[q];
-    bool keep = q < np;
-    for (int r = q + 1; r < np; ++r) keep = keep && (job == 1 ? sh_l[r] : sh_e[r]) != key;
-    const unsigned long long mask = __ballot(keep);
-    if (keep) sh_pick[__popcll(mask & ((1ull << q) - 1ull))] = q;
-    const int npick = __popcll(mask);
-    if (q < kFixChunk) sh_pick[npick + q] = 0;   // (padding of the last chunk: reads stay inside the ring)
-    if (q == 0) sh_npick = npick;
-  }
+  if (job != 2 && threadIdx.x < 64) fix_pick_chains(job == 1 ? sh_l : sh_e, np, sh_pick, &sh_npick);
   __syncthreads();
   const int npick = job == 2 ? 0 : sh_npick;
   if (job != 2 && s0 >= npick) return;
@@ -3662,7 +3671,10 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
       }
 #pragma unroll
       for (int q = 0; q < kFixChunk; ++q)
-        if (q < ns) A[(int64_t)t * ld + sh_e[pk[q]]] = v[q];
+        if (q < ns) {
+          if (img_col) img_col[(int64_t)(s0 + q) * mp + t] = v[q];
+          else A[(int64_t)t * ld + sh_e[pk[q]]] = v[q];
+        }
     }
   } else if (job == 1) {  // pivot rows of pending pivots s0 .. (those that live on this shard), all columns
     for (int idx = threadIdx.x; idx < np * kFixChunk; idx += blockDim.x) {
@@ -3718,7 +3730,10 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
 #pragma unroll
       for (int q = 0; q < kFixChunk; ++q) {
         const int i = q < ns ? sh_l[pk[q]] : -1;
-        if (i >= 0 && i < m_local) A[(int64_t)i * ld + t] = v[q];
+        if (i >= 0 && i < m_local) {
+          if (img_row) img_row[(int64_t)(s0 + q) * ld + t] = v[q];
+          else A[(int64_t)i * ld + t] = v[q];
+        }
       }
     }
   } else {  // b of every local row (LPState.java:164 / :146)
@@ -3740,6 +3755,58 @@ __global__ __launch_bounds__(256) void k_block_fixup(double* __restrict__ A, int
         }
       }
       b[t] = bi;
+    }
+  }
+}
+
+// Behind the sweep of the overlapped loop: the entering columns (job 0) and pivot rows (job 1) that k_block_fixup computed
+// beside it go from the images into the tableau.  grid = (ceil(max(m, ld)/256), ceil(K / 8), 2), the chains found as there.
+__global__ __launch_bounds__(256) void k_block_fixup_scatter(double* __restrict__ A, int64_t ld, int m_local, int row0,
+                                                             const double* __restrict__ img_col,
+                                                             const double* __restrict__ img_row, int64_t mp,
+                                                             const LpxCtl* __restrict__ ring, int kmax,
+                                                             long long* __restrict__ clk) {
+  if (clk && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+    const unsigned x = xcc_id() & 7u;
+    clk[x * 4 + 2] = __builtin_amdgcn_s_memtime(); clk[x * 4 + 3] = wall_clock64();
+  }
+  __shared__ int sh_key[kBlockMax], sh_pick[kBlockMax + kFixChunk];
+  __shared__ int sh_np, sh_npick;
+  const int s0 = blockIdx.y * kFixChunk, job = blockIdx.z;
+  if ((int64_t)blockIdx.x * blockDim.x >= (job == 1 ? ld : (int64_t)m_local)) return;
+  const int np = ring_count(ring, kBlockMax, kmax, &sh_np);
+  if (s0 >= np) return;
+  if ((int)threadIdx.x < kBlockMax) {
+    const bool live = (int)threadIdx.x < np;
+    const LpxCtl& q = ring[live ? threadIdx.x : 0];
+    sh_key[threadIdx.x] = live ? (job == 1 ? q.l - row0 : q.e_cur) : -1;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) fix_pick_chains(sh_key, np, sh_pick, &sh_npick);
+  __syncthreads();
+  const int npick = sh_npick;
+  if (s0 >= npick) return;
+  const int ns = min(kFixChunk, npick - s0);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double v[kFixChunk];
+  if (job == 0) {
+    if (t >= m_local) return;
+#pragma unroll
+    for (int q = 0; q < kFixChunk; ++q) v[q] = q < ns ? img_col[(int64_t)(s0 + q) * mp + t] : 0.0;
+#pragma unroll
+    for (int q = 0; q < kFixChunk; ++q)
+      if (q < ns) A[(int64_t)t * ld + sh_key[sh_pick[s0 + q]]] = v[q];
+  } else {
+    if (t >= (int)ld) return;
+#pragma unroll
+    for (int q = 0; q < kFixChunk; ++q) {
+      const int i = q < ns ? sh_key[sh_pick[s0 + q]] : -1;
+      v[q] = (i >= 0 && i < m_local) ? img_row[(int64_t)(s0 + q) * ld + t] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < kFixChunk; ++q) {
+      const int i = q < ns ? sh_key[sh_pick[s0 + q]] : -1;
+      if (i >= 0 && i < m_local) A[(int64_t)i * ld + t] = v[q];
     }
   }
 }
@@ -4118,7 +4185,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
 #undef LPX_PRE_MFMA64
 #endif
 #define LPX_PRE_MFMA642(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
+    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, 33);
     LPX_EACH_NT_OOP(LPX_PRE_MFMA642)
 #undef LPX_PRE_MFMA642
 #endif
@@ -4136,7 +4203,9 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
 #undef LPX_PRE_TILES
 #undef LPX_EACH_NT_OOP
   hipLaunchKernelGGL(k_block_fixup, dim3(1, 1, 3), dim3(256), 0, s, A, ld, 0, 0, 0, B.b, R.prow, R.col, R.col0, R.row0,
-                     R.mp, R.up, 0, B.b, (long long*)nullptr);
+                     R.mp, R.up, 0, B.b, (long long*)nullptr, (double*)nullptr, (double*)nullptr);
+  hipLaunchKernelGGL(k_block_fixup_scatter, dim3(1, 1, 2), dim3(256), 0, s, A, ld, 0, 0, (const double*)nullptr, (const double*)nullptr,
+                     R.mp, R.up, 0, (long long*)nullptr);
   ChainArgs P{};   // nb = 0: every workgroup returns after reading the loop state (no barrier, nothing published)
   P.ctl = B.ctl; P.up = R.up; P.nb = 0;
   P.bar = R.chain_bar; P.bar_next = R.chain_bar + 32;
@@ -4234,7 +4303,7 @@ static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local
 // blocks of 33..64 on the matrix cores (fused arithmetic only): one wave per SIMD, G workgroups per group of four
 // 64-column sub-strips, 16-row tiles pulled from the sub-strip's ticket counter
 static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                                hipStream_t s, int slots = 256, bool two_waves = false) {
+                                hipStream_t s, int slots = 256, bool two_waves = false, int kmin = 33) {
   const int nstrips_full = (int)(B.ld / 512);
   const int ngroups = nstrips_full * 2;
   const int ntiles = m_local / 16;
@@ -4247,7 +4316,7 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
     const dim3 grid2(ng2 * G2), block2(256);
 #define LPX_LAUNCH_MFMA642(NT_, OOP_)                                                                               \
     hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), grid2, block2, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                       nstrips_full, R.col_packed, R.tickets)
+                       nstrips_full, R.col_packed, R.tickets, kmin)
     if (A_src) { if (nt) LPX_LAUNCH_MFMA642(true, true); else LPX_LAUNCH_MFMA642(false, true); }
     else { if (nt) LPX_LAUNCH_MFMA642(true, false); else LPX_LAUNCH_MFMA642(false, false); }
 #undef LPX_LAUNCH_MFMA642
@@ -4311,7 +4380,7 @@ const char* sweep_kernel_name(int code) {
 // rows_per_wg <= 0: chosen here (see choose_sweep_rows); cus: CUs the stream may use (0: the whole device)
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep,
-                       int cus, int form, int* kernel_used) {
+                       int cus, int form, int* kernel_used, const FixSide* side) {
   int used = kSweepNone;
   if (kernel_used) *kernel_used = used;
   if (K < 1) return 0;
@@ -4319,6 +4388,16 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  // The fix-up's chains read ring values only (and b, which the sweep leaves alone): with a side stream they are computed
+  // BESIDE the sweep into the images of this ring half, and only their copy into the tableau follows the sweep.
+  const bool side_fix = side && side->stream && R.fix_col && R.fix_row;
+  if (side_fix) {
+    const int gxf = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
+    (void)hipStreamWaitEvent(side->stream, side->ready, 0);
+    hipLaunchKernelGGL(k_block_fixup, dim3(gxf, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, side->stream, B.A, B.ld, n, m_local, row0,
+                       B.b, R.prow, R.col, R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, (long long*)nullptr, R.fix_col, R.fix_row);
+    (void)hipEventRecord(side->done, side->stream);
   }
   if (K <= 16) {
     // tiles of a few rows (k_update_tiles): up to K = 16 the sweep is HBM-bound and 16-row tiles stream best
@@ -4347,13 +4426,13 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     const bool pull = geom && form != 1 && R.tickets && R.col_packed;   // round 3 / 4: blocks of 33..64 valid pivots
     const bool pipe = geom && !pull && K == 64;                         // round 2: full blocks of 64 only
     const bool one = pull && form != 2;
-    const bool mfma_form = form == 0 || form == 4;
+    [[maybe_unused]] const bool mfma_form = form == 0 || form == 4;
     const bool mfma2 = form == 0;
 #else
     const bool pull = geom && R.tickets && R.col_packed;
     const bool pipe = false;
     const bool one = pull;
-    const bool mfma_form = form != 3;   // (3: k_sweep64_one in the fused arithmetic too)
+    [[maybe_unused]] const bool mfma_form = form != 3;   // (3: k_sweep64_one in the fused arithmetic too)
     const bool mfma2 = true;
 #endif
     bool mfma = false;
@@ -4361,9 +4440,12 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     mfma = one && mfma_form && m_local % 16 == 0 && 16 * B.ld * 8 + 1024 < ((int64_t)1 << 32);
 #endif
     int rows64 = 0;
+    // the matrix-core sweep over whole strips takes ANY number of valid pivots: no generic launches behind it (they cost
+    // two launches and their gaps per block, ~20 us of a 2.1 ms block at cfg4, only to find nothing to do)
+    const bool whole = mfma && mfma2 && B.ld % 512 == 0;
     if (mfma) {
 #if LPX_FUSED
-      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, mfma2);
+      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, mfma2, whole ? 1 : 33);
 #endif
       rows64 = 16;
     } else if (one) {
@@ -4385,8 +4467,10 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     const int complement = pull ? 34 : (pipe ? 65 : 0);
     int rows = choose_sweep_rows(m_local, B.ld, 32, cus);
     while (rows > kSweepChunk && (int64_t)rows * B.ld * 8 >= (int64_t)1 << 32) rows -= kSweepChunk;
-    launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, complement, 0);
-    launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, complement, 32);
+    if (!whole) {
+      launch_sweep_k<32>(B, R, m_local, K, rows, nt, A_src, s, complement, 0);
+      launch_sweep_k<32>(B, R, m_local, K, rows, nt, nullptr, s, complement, 32);
+    }
     rows_per_wg = (pull || pipe) ? rows64 : rows;
     used = mfma ? (mfma2 ? kSweepMfma642 : kSweepMfma64) : one ? kSweepOne64 : (pull ? kSweepPull64 : (pipe ? kSweepPipe64 : kSweepMulti));
   } else if (K < kMaxBlock && !(m_local % 4 == 0 && B.ld >= 512)) {
@@ -4443,8 +4527,14 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
   // fix-up must not pair its stamp with a front stamp of an older launch (lpx_state_info.sweep_clock_mhz then says 0)
   const bool probed = used == kSweepPull || used == kSweepPull64 || used == kSweepOne64 || used == kSweepMfma64 || used == kSweepMfma642;
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
-  hipLaunchKernelGGL(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
-                     R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, probed ? R.clk : nullptr);
+  if (side_fix) {   // the chains were computed beside the sweep (launched above): only their copy into the tableau is left
+    (void)hipStreamWaitEvent(s, side->done, 0);
+    hipLaunchKernelGGL(k_block_fixup_scatter, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 2), dim3(256), 0, s, B.A, B.ld, m_local, row0,
+                       R.fix_col, R.fix_row, R.mp, R.up, K, probed ? R.clk : nullptr);
+  } else {
+    hipLaunchKernelGGL(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
+                       R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, probed ? R.clk : nullptr, nullptr, nullptr);
+  }
   if (!probed && R.clk) (void)hipMemsetAsync(R.clk, 0, 256, s);
   return rows_per_wg;
 }

@@ -897,6 +897,19 @@ def test_decision_cus_option_vs_fp64_oracle(lps, oracle, cus, resident):
         assert info["chain_resident_max"] == resident and info["chain_wgs"] in (min(48, resident), min(49, resident)), info
 
 
+@pytest.mark.parametrize("side", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape,block", [((4096, 12288), 32), ((2048, 4096), 64), ((1000, 1500), 64)])
+def test_fixup_beside_or_behind_the_sweep_vs_oracle(lps, oracle, shape, block, side):
+    """Option fixup_side (LPX_OPT_FIXUP_SIDE): the entering columns and pivot rows of a block recomputed from the ring
+    (LPState.java:139-164) behind the block's sweep (0) or beside it into images that only a copy kernel takes into the
+    tableau afterwards (1: on the sweep's CUs, 2: the decisions' CUs — the default —, 3: no mask).  Three full blocks and
+    tails (a second call continues on the swapped buffers) against the oracle of the arithmetic mode, bit for bit; the
+    1000 x 1500 case has partial strips and rows that are not a multiple of 4 (generic sweep kernels)."""
+    m, n = shape
+    info = _timed_form_vs_oracle(lps, oracle, m, n, (3 * block + 7, block + 3), options={"fixup_side": side, "block": block})
+    assert info["block"] == block and info["overlapped"] == 1
+
+
 def test_cfg3_one_pass_form_30_pivots_vs_fp64_oracle(lps, oracle):
     """The roofline kernel of north_star itself at HBM size: one pass per pivot (k_select_pivot + k_update<1, nt>, the
     form `bench.py --option block=1` times at 6.3 TB/s) for 30 pivots at cfg3 against the fp64 oracle."""
