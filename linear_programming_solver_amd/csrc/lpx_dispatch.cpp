@@ -10,9 +10,9 @@ namespace lpxk {
 
 #define LPX_PICK(B, f) ((B).fused ? fused::f : plain::f)
 
-void launch_entering(const Buffers& B, int n, hipStream_t s) { LPX_PICK(B, launch_entering)(B, n, s); }
-void launch_entering_dantzig(const Buffers& B, int n, bool seed, hipStream_t s) {
-  LPX_PICK(B, launch_entering_dantzig)(B, n, seed, s);
+void launch_entering(const Buffers& B, int n, hipStream_t s, const LoopStart& start) { LPX_PICK(B, launch_entering)(B, n, s, start); }
+void launch_entering_dantzig(const Buffers& B, int n, bool seed, hipStream_t s, const LoopStart& start) {
+  LPX_PICK(B, launch_entering_dantzig)(B, n, seed, s, start);
 }
 void launch_ratio_gather(const Buffers& B, int m_local, int row0, const Geometry& g, int forced_e, hipStream_t s) {
   LPX_PICK(B, launch_ratio_gather)(B, m_local, row0, g, forced_e, s);

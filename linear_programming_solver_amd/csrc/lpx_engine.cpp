@@ -141,13 +141,19 @@ static void apply_layout_options(lpx_state* s) {
   s->info.nontemporal = s->nontemporal ? 1 : 0;
 }
 
-int sync_ctl_to_host(lpx_state* s) {
+// The loop state travels to the host mirror behind everything enqueued on the handle's stream so far; no wait.
+static int enqueue_ctl_fetch(lpx_state* s) {
   HIP_TRY(hipMemcpyAsync(s->h_ctl, s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
   // a bounded wait inside a sweep kernel that ran out sets a device word: it travels with the loop state (no extra sync)
   unsigned* const fw = lpxk::sweep_fail_word(s->R, s->B.ld);
   unsigned* const h_fw = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(s->h_ctl) + sizeof(LpxCtl));
   if (fw) HIP_TRY(hipMemcpyAsync(h_fw, fw, sizeof(unsigned), hipMemcpyDeviceToHost, s->stream));
-  HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+// ... and once the stream has been waited for: did a sweep kernel report a wait that ran out?
+static int check_fetched_fail_word(lpx_state* s) {
+  unsigned* const fw = lpxk::sweep_fail_word(s->R, s->B.ld);
+  unsigned* const h_fw = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(s->h_ctl) + sizeof(LpxCtl));
   if (fw && *h_fw) {
     const unsigned f = *h_fw;
     *h_fw = 0;
@@ -156,6 +162,11 @@ int sync_ctl_to_host(lpx_state* s) {
                                       std::to_string(f) + "); the tableau of this handle is not valid");
   }
   return 0;
+}
+int sync_ctl_to_host(lpx_state* s) {
+  if (int rc = enqueue_ctl_fetch(s)) return rc;
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return check_fetched_fail_word(s);
 }
 
 int push_ctl(lpx_state* s) {
@@ -437,9 +448,9 @@ extern "C" int lpx_profile_read(lpx_state* s, int64_t* launches, double* total_m
 }
 
 // entering scan at the start of a loop / for getEntering(), honouring the handle's pricing rule
-void launch_seed_entering(lpx_state* s) {
-  if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, true, s->stream);
-  else lpxk::launch_entering(s->B, s->n, s->stream);
+void launch_seed_entering(lpx_state* s, const lpxk::LoopStart& start) {
+  if (s->pricing == 1) lpxk::launch_entering_dantzig(s->B, s->n, true, s->stream, start);
+  else lpxk::launch_entering(s->B, s->n, s->stream, start);
 }
 
 extern "C" int lpx_state_set_pricing(lpx_state* s, int32_t pricing) {
@@ -825,11 +836,11 @@ int ensure_fix_side(lpx_state* s, int mode) {
 //     sweep stream :          | sweep 0 | sweep 1 | ...                     ring half it overwrites)
 //                                                                sweep k   waits for chain k (and follows sweep k-1)
 // Same arithmetic, same order, per tableau entry: bit-identical to the serial forms.
-static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
+static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots, const lpxk::LoopStart& start) {
   if (int rc = ensure_block_ring(s)) return rc;
   if (int rc = ensure_spare_tableau(s)) return rc;
   if (int rc = ensure_overlap_streams(s)) return rc;
-  launch_seed_entering(s);
+  launch_seed_entering(s, start);
   HIP_TRY(hipEventRecord(s->ev_ov_join[0], s->stream));
   HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_join[0], 0));
   HIP_TRY(hipStreamWaitEvent(s->ov_sweep, s->ev_ov_join[0], 0));
@@ -921,19 +932,22 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots) {
     std::swap(s->B.A, s->A2);
     std::swap(s->B.b, s->b2);
   }
+  if (rc == 0) rc = enqueue_ctl_fetch(s);   // the loop state comes back with the same wait
   hipError_t e2 = hipStreamSynchronize(s->stream);
   if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
   return rc;
 }
 
 // LPSolver.simplex's loop with K pivot decisions per pass over the tableau (bit-identical results).
-static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
+// start: what the loop's first launch resets in the loop state (lpxk::LoopStart).  On return (0) the host mirror of the
+// loop state is current: it was fetched behind the last launch, in front of the one wait at the end.
+static int blocked_loop(lpx_state* s, int K, int64_t max_pivots, const lpxk::LoopStart& start) {
   // a budget that fits one block has nothing to run beside: the serial form below gives its decisions and its sweep
   // the whole chip (20 pivots, the bench driver's command: cfg3 24.7k vs 20.0k pivots/s, same box)
   const bool one_block = max_pivots >= 0 && max_pivots + 1 <= K;
   if (s->opt[LPX_OPT_CHAIN] != 0 && s->opt[LPX_OPT_OVERLAP] != 0 && s->row0 == 0 && s->m == s->m_global && !one_block) {
     // the overlapped form needs a second tableau: a tableau of more than half the HBM keeps the in-place form
-    if (s->A2 || ensure_spare_tableau(s) == 0) return blocked_loop_overlapped(s, K, max_pivots);
+    if (s->A2 || ensure_spare_tableau(s) == 0) return blocked_loop_overlapped(s, K, max_pivots, start);
     (void)hipGetLastError();
     if (s->A_base[1]) { (void)hipFree(s->A_base[1]); s->A_base[1] = nullptr; }
     if (s->b_base[1]) { (void)hipFree(s->b_base[1]); s->b_base[1] = nullptr; }
@@ -941,7 +955,7 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
     s->b2 = nullptr;
   }
   if (int rc = ensure_block_ring(s)) return rc;
-  launch_seed_entering(s);
+  launch_seed_entering(s, start);
   hipEvent_t* evs = s->ev_batch;
   LpxCtl* h2 = s->h_snap;
   int64_t decided = 0;  // decisions issued (each either pivots or reports the end)
@@ -981,7 +995,9 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
     if (nb > 0 && !probe_only) {
       if (int rc = launch_sweep_profiled(s, nb)) return rc;
     }
-    if (!(fused && nb > 0))  // the fused launch writes the snapshot itself
+    // (the fused launch writes the snapshot itself; a block of no decisions — the budget is spent, the decision that says
+    // so is in the block before — has nothing new to show and its snapshot is never looked at)
+    if (!fused)
       HIP_TRY(hipMemcpyAsync(&h2[slot], s->B.ctl, sizeof(LpxCtl), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipEventRecord(evs[slot], s->stream));
     return 0;
@@ -996,6 +1012,7 @@ static int blocked_loop(lpx_state* s, int K, int64_t max_pivots) {
     if (h2[cur].status != lpxk::kRunning) break;
     cur ^= 1;
   }
+  if (rc == 0) rc = enqueue_ctl_fetch(s);   // the loop state comes back with the same wait
   hipError_t e2 = hipStreamSynchronize(s->stream);
   if (rc == 0 && e2 != hipSuccess) rc = fail(LPX_DEVICE_ERROR, hipGetErrorString(e2));
   return rc;
@@ -1158,11 +1175,16 @@ extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivot
                                 int32_t* track_slot) {
   if (int rc = require_single(s, "lpx_simplex_loop")) return rc;
   HIP_TRY(hipSetDevice(s->device));
-  if (int rc = set_running(s, max_pivots, track_slot ? *track_slot : -1)) return rc;
   const int K = choose_block(s);
   if (K >= 2) {
-    if (int rc = blocked_loop(s, K, max_pivots)) return rc;
-    if (int r2 = sync_ctl_to_host(s)) return r2;
+    // one host round trip per call: the first launch of the loop starts the loop state over on the device (no
+    // read-modify-write of the host mirror in front), the last copy brings it back in front of the loop's own final wait
+    lpxk::LoopStart start;
+    start.reset = 1;
+    start.track = track_slot ? *track_slot : -1;
+    start.max_pivots = max_pivots;
+    if (int rc = blocked_loop(s, K, max_pivots, start)) return rc;
+    if (int r2 = check_fetched_fail_word(s)) return r2;
     if (pivots_done) *pivots_done = s->h_ctl->pivots;
     if (status) *status = s->h_ctl->status;
     if (track_slot) *track_slot = s->h_ctl->track;
@@ -1174,6 +1196,7 @@ extern "C" int lpx_simplex_loop(lpx_state* s, int64_t max_pivots, int64_t* pivot
                                         " workgroups resident?  The tableau of this handle is not valid");
     return 0;
   }
+  if (int rc = set_running(s, max_pivots, track_slot ? *track_slot : -1)) return rc;
   // seed: entering scan + strided column gather / partials for the first pivot
   launch_seed_entering(s);
   lpxk::launch_ratio_gather(s->B, s->m, s->row0, s->g, -1, s->stream);

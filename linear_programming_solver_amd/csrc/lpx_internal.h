@@ -113,7 +113,7 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
                           const double* A_src, const double* b_src, const lpxk::FixSide* side = nullptr);
 int ensure_fix_side(lpx_state* s, int mode);   // ov_fix[mode], ev_ov_fix and the ring's images (R.fix_col / R.fix_row)
 lpxk::BlockRing ring_half(const lpx_state* s, int h);
-void launch_seed_entering(lpx_state* s);
+void launch_seed_entering(lpx_state* s, const lpxk::LoopStart& start = lpxk::LoopStart{});   // start.reset: also starts the loop state over
 int launch_update_profiled(lpx_state* s, const double* prow = nullptr, const LpxCtl* up = nullptr,
                            const Buffers* Bin = nullptr, double* A_out = nullptr, double* b_out = nullptr);
 

@@ -38,6 +38,9 @@ struct LpxCtl {
   int64_t max_pivots;  // budget for `pivots` (<0: unlimited)
 };
 
+// What the first launch of a loop call resets in LpxCtl (k_entering / k_entering_dantzig): see loop_start().
+struct LoopStart { int32_t reset = 0; int32_t track = -1; int64_t max_pivots = -1; };
+
 struct Geometry {
   int U;              // double2 per thread per row in k_update (strip width = 512*U columns)
   int rows_per_tile;  // rows handled by one k_update block

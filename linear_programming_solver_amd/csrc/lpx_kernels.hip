@@ -115,9 +115,24 @@ __device__ __forceinline__ double ratio_of(double a, double bi) {
 
 // ------------------------------------------------------------------------------------------------ k_entering
 // getEntering(): first slot with c[j] > 1e-9 (LPState.java:274-285).  One workgroup.
-__global__ __launch_bounds__(1024) void k_entering(const double* __restrict__ c, int n, LpxCtl* ctl) {
+// start.reset = 1 (first launch of a loop call): the loop state starts over here — status, counters, budget, tracked slot —
+// instead of by a read-modify-write of the host mirror (two small copies and a host round trip in front of every call).
+__device__ __forceinline__ void loop_start(LpxCtl* ctl, const LoopStart& st) {
+  if (threadIdx.x == 0) {
+    ctl->status = kRunning;
+    ctl->do_update = 0;
+    ctl->pivots = 0;
+    ctl->max_pivots = st.max_pivots;
+    ctl->track = st.track;
+    ctl->e_min = INT_MAX;
+    ctl->ticket = 0;
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(1024) void k_entering(const double* __restrict__ c, int n, LpxCtl* ctl, const LoopStart start) {
   __shared__ int sh[16];
-  if (ctl->status != kRunning) return;
+  if (start.reset) loop_start(ctl, start);
+  else if (ctl->status != kRunning) return;
   int best = INT_MAX;
   for (int j = threadIdx.x; j < n; j += blockDim.x)
     if (c[j] > kEps) { best = j; break; }  // per-thread indices ascend, the first hit is this thread's min
@@ -133,9 +148,10 @@ __global__ __launch_bounds__(1024) void k_entering(const double* __restrict__ c,
 // decision and overrides ctl->e_next (k_select_pivot / k_commit have already set status = OPTIMAL when no
 // c[j] > 1e-9 exists, which is rule-independent).  `seed` = 1: also decide OPTIMAL (start of a loop).
 __global__ __launch_bounds__(1024) void k_entering_dantzig(const double* __restrict__ c, int n, LpxCtl* ctl,
-                                                           int seed) {
+                                                           int seed, const LoopStart start) {
   __shared__ RatioRow sh[16];
-  if (ctl->status != kRunning) return;
+  if (start.reset) loop_start(ctl, start);
+  else if (ctl->status != kRunning) return;
   RatioRow best{-kInf, INT_MAX, 0};  // reuse the (value,index) lexmin machinery on (-c[j], j)
   best.ratio = kInf;
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
@@ -3921,13 +3937,13 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-void launch_entering(const Buffers& B, int n, hipStream_t s) {
-  hipLaunchKernelGGL(k_entering, dim3(1), dim3(1024), 0, s, B.c, n, B.ctl);
+void launch_entering(const Buffers& B, int n, hipStream_t s, const LoopStart& start) {
+  hipLaunchKernelGGL(k_entering, dim3(1), dim3(1024), 0, s, B.c, n, B.ctl, start);
 }
 
-void launch_entering_dantzig(const Buffers& B, int n, bool seed, hipStream_t s) {
+void launch_entering_dantzig(const Buffers& B, int n, bool seed, hipStream_t s, const LoopStart& start) {
   // 256 threads: this kernel may run beside the row update on the comm stream (look-ahead pipeline)
-  hipLaunchKernelGGL(k_entering_dantzig, dim3(1), dim3(256), 0, s, B.c, n, B.ctl, seed ? 1 : 0);
+  hipLaunchKernelGGL(k_entering_dantzig, dim3(1), dim3(256), 0, s, B.c, n, B.ctl, seed ? 1 : 0, start);
 }
 
 void launch_ratio_gather(const Buffers& B, int m_local, int row0, const Geometry& g, int forced_e, hipStream_t s) {
@@ -4128,7 +4144,12 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
 // then spare slots; the LAST slot is never a counter — it is the word a pull kernel sets when a bounded wait ran out.
 int64_t sweep_ticket_slots(int64_t ld) { return std::max<int64_t>(ld / 64, 4) + 4; }   // (k_sweep64_one: a counter per 64 columns)
 unsigned* sweep_fail_word(const BlockRing& R, int64_t ld) {
+#ifdef LPX_WITH_VARIANTS   // (the only kernel that sets it, k_sweep64_pull, is in the variants library only)
   return R.tickets ? R.tickets + (sweep_ticket_slots(ld) - 1) * 32 : nullptr;
+#else
+  (void)R; (void)ld;
+  return nullptr;
+#endif
 }
 
 void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) {
