@@ -11,4 +11,4 @@ for W in cfg3 cfg4; do
   timeout -k 10 120 python scripts/chain_trace_fine.py $W 256 fused=1 2>&1 | tail -3 >> $O
 done
 cat $O
-bash scripts/r04_ac.sh
+bash scripts/calls/r04_ac.sh

@@ -4,4 +4,4 @@
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests/test_gpu_multi.py -x -q > gpurun_out/r05_g_multi.log 2>&1
 tail -5 gpurun_out/r05_g_multi.log
-bash scripts/r05_f.sh
+bash scripts/calls/r05_f.sh
