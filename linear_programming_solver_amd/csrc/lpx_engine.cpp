@@ -193,6 +193,7 @@ static void free_block_ring(lpx_state* s) {
   (void)hipFree(s->R.census);
   (void)hipFree(const_cast<double*>(s->R.zeros));
   (void)hipFree(s->R.tickets);
+  (void)hipFree(s->R.sweep_fail);
   (void)hipFree(s->R.clk);
   (void)hipFree(s->R.col_packed);
   (void)hipFree(s->R.fix_col);
@@ -240,6 +241,7 @@ void free_state(lpx_state* s) {
   for (hipEvent_t e : s->ev_ov_join) if (e) (void)hipEventDestroy(e);
   for (hipStream_t t : s->ov_fix) if (t) (void)hipStreamDestroy(t);
   for (hipEvent_t e : s->ev_ov_fix) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : s->ev_ov_pack) if (e) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
   delete s;
 }
@@ -588,12 +590,15 @@ static int build_block_ring(lpx_state* s) {
   HIP_TRY(hipMemsetAsync(const_cast<double*>(s->R.zeros), 0, 256, s->stream));
   // k_sweep32_pull: a ticket counter per 128-column sub-strip (128 bytes apart) and the block's multipliers packed by
   // batches of 4 rows (1 KiB each)
-  HIP_TRY(hipMalloc((void**)&s->R.tickets, (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128));
-  HIP_TRY(hipMemsetAsync(s->R.tickets, 0, (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128, s->stream));
+  // (both once per ring half: the pack kernel of block k runs while the sweep of block k-1 still pulls and reads its own)
+  HIP_TRY(hipMalloc((void**)&s->R.tickets, 2 * (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128));
+  HIP_TRY(hipMemsetAsync(s->R.tickets, 0, 2 * (size_t)lpxk::sweep_ticket_slots(s->B.ld) * 128, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.sweep_fail, 128));
+  HIP_TRY(hipMemsetAsync(s->R.sweep_fail, 0, 128, s->stream));
   HIP_TRY(hipMalloc((void**)&s->R.clk, 256));
   HIP_TRY(hipMemsetAsync(s->R.clk, 0, 256, s->stream));
-  HIP_TRY(hipMalloc((void**)&s->R.col_packed, (size_t)(mp / 4 + 1) * 2048));
-  HIP_TRY(hipMemsetAsync(s->R.col_packed, 0, (size_t)(mp / 4 + 1) * 2048, s->stream));
+  HIP_TRY(hipMalloc((void**)&s->R.col_packed, 2 * (size_t)(mp / 4 + 1) * 2048));
+  HIP_TRY(hipMemsetAsync(s->R.col_packed, 0, 2 * (size_t)(mp / 4 + 1) * 2048, s->stream));
   HIP_TRY(hipMalloc((void**)&s->d_cand, (size_t)(LPX_CAND_HEADER + s->B.ld) * sizeof(double)));
   HIP_TRY(hipMemsetAsync(s->R.prow, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   HIP_TRY(hipMemsetAsync(s->R.col, 0, K * (size_t)mp * sizeof(double), s->stream));
@@ -720,6 +725,8 @@ lpxk::BlockRing ring_half(const lpx_state* s, int h) {
   R.col0 += o * R.mp;
   if (R.fix_col) R.fix_col += o * R.mp;
   if (R.fix_row) R.fix_row += o * s->B.ld;
+  if (R.col_packed) R.col_packed += (int64_t)h * (R.mp / 4 + 1) * (2048 / sizeof(double));
+  if (R.tickets) R.tickets += (int64_t)h * lpxk::sweep_ticket_slots(s->B.ld) * 32;
   R.up += o;
   return R;
 }
@@ -807,8 +814,10 @@ int ensure_fix_side(lpx_state* s, int mode) {
     HIP_TRY(hipMemsetAsync(s->R.fix_col, 0, K * (size_t)s->R.mp * sizeof(double), s->stream));
     HIP_TRY(hipMemsetAsync(s->R.fix_row, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   }
-  for (int k = 0; k < 2; k++)
+  for (int k = 0; k < 2; k++) {
     if (!s->ev_ov_fix[k]) HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_fix[k], hipEventDisableTiming));
+    if (!s->ev_ov_pack[k]) HIP_TRY(hipEventCreateWithFlags(&s->ev_ov_pack[k], hipEventDisableTiming));
+  }
   if (s->ov_fix[mode]) return 0;
   bool made = false;
   if (s->ov_masked && mode != 3) {
@@ -906,7 +915,9 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots, cons
     // (the side stream: chains k start when decisions k are through — their ring half and their image half are free by
     // then: chain k itself waited for sweep k-2, which ends with the copy of those images —, and run in stream order, so
     // the b they read is the one chains k-1 wrote)
-    const lpxk::FixSide side{fix_mode > 0 ? s->ov_fix[fix_mode] : nullptr, s->ev_ov_chain[h], s->ev_ov_fix[h]};
+    // The sweep's pack kernel goes the same way, in front of the chains: its multiplier buffer and ticket counters are the
+    // ring half's own, free since sweep k-2.
+    const lpxk::FixSide side{fix_mode > 0 ? s->ov_fix[fix_mode] : nullptr, s->ev_ov_chain[h], s->ev_ov_fix[h], s->ev_ov_pack[h]};
     if (int rc = launch_sweep_profiled(s, nb, s->ov_sweep, Bdst, ring_half(s, h), Abuf[h], bbuf[h], fix_mode > 0 ? &side : nullptr)) return rc;
     HIP_TRY(hipEventRecord(s->ev_ov_sweep[h], s->ov_sweep));
     decided += nb;

@@ -61,6 +61,7 @@ struct lpx_state {
   // the fix-up's chains beside the sweep (LPX_OPT_FIXUP_SIDE = 1..3: on the sweep's CUs, the decisions' CUs, all CUs)
   hipStream_t ov_fix[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_ov_fix[2] = {nullptr, nullptr};     // chains of block k done (the copy kernel waits for it)
+  hipEvent_t ev_ov_pack[2] = {nullptr, nullptr};    // multipliers of block k packed on the side stream (sweep k waits for it)
   double* d_cand = nullptr;         // candidate record of the single-GPU blocked loop (8 + n doubles)
   LpxCtl* h_ctl = nullptr;          // pinned mirror
   LpxCtl* h_snap = nullptr;         // 2 pinned snapshots for the batched loop (batch k+1 in flight while k is read)

@@ -87,7 +87,8 @@ struct BlockRing {  // every ring has 2 * kBlockMax slots: two halves, one per b
   double* fix_col;         // overlapped loop: images of the fix-up's entering columns [chain][mp] (NULL: the fix-up follows the sweep and writes the tableau itself)
   double* fix_row;         // ... and of its pivot rows [chain][ld]; both 2 x kBlockMax chains like the rings
   double* col_packed;      // k_sweep32_pull: the block's multipliers as [batch of 4 rows][pivot][row]: (mp / 4) x 1 KiB (2 KiB for blocks of 64)
-  unsigned* tickets;       // k_sweep32_pull: one batch counter per 128-column sub-strip, 128 bytes apart (ld / 128 of them)
+  unsigned* tickets;       // k_sweep32_pull: one batch counter per 128-column sub-strip, 128 bytes apart (ld / 128 of them); like col_packed once per ring half
+  unsigned* sweep_fail;    // the word a pull kernel sets when a bounded wait ran out (k_sweep64_pull: variants library only)
   long long* clk;          // clock probe of the last pulled sweep, per XCD x: clk[4 x + 0..1] = {s_memtime, 100 MHz} in front of it, [4 x + 2..3] behind it
   const double* zeros;     // 256 bytes of +0.0: what k_sweep32_dma's multiplier DMA reads for the identity steps of a partly filled block
   // shards of an lpx_multi only (else NULL): written by the peers' decision kernels
@@ -113,7 +114,9 @@ struct MgPeers {
 // which kernel swept the bulk of the tableau (lpx_state_info.sweep_kernel)
 enum SweepKernel { kSweepNone = 0, kSweepTiles = 1, kSweepMulti = 2, kSweepSteady = 3, kSweepPipe64 = 4, kSweepDma = 5, kSweepPull = 6, kSweepPull64 = 7, kSweepOne64 = 8, kSweepMfma64 = 9, kSweepMfma642 = 10 };
 // The fix-up of a block beside its sweep (launch_block_sweep): where its chains run and the two events that tie them in.
-struct FixSide { hipStream_t stream; hipEvent_t ready, done; };
+// ready: the block's decisions are through (the side stream waits for it); packed: the sweep's pack kernel is through (may be
+// NULL: it then runs on the sweep's stream); done: the fix-up's chains are through (the copy kernel waits for it).
+struct FixSide { hipStream_t stream; hipEvent_t ready, done, packed; };
 struct RestoreEntry { int32_t is_basic; int32_t index; double k; };  // index = row r (basic) or post-drop slot
 
 // ---- launch wrappers --------------------------------------------------------------------------------------------

@@ -1014,11 +1014,12 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
 // when the first ring is built — one workgroup each, with arguments that make it return at once (no pending pivots,
 // no rows, no decisions) and touch nothing but the ring's own words.
 // The ticket buffer: one 128-byte slot per 128-column sub-strip (at least the four the preparing launches pull from),
-// then spare slots; the LAST slot is never a counter — it is the word a pull kernel sets when a bounded wait ran out.
+// then spare slots.  (The word a pull kernel sets when a bounded wait ran out is BlockRing::sweep_fail.)
 int64_t sweep_ticket_slots(int64_t ld) { return std::max<int64_t>(ld / 64, 4) + 4; }   // (k_sweep64_one: a counter per 64 columns)
 unsigned* sweep_fail_word(const BlockRing& R, int64_t ld) {
 #ifdef LPX_WITH_VARIANTS   // (the only kernel that sets it, k_sweep64_pull, is in the variants library only)
-  return R.tickets ? R.tickets + (sweep_ticket_slots(ld) - 1) * 32 : nullptr;
+  (void)ld;
+  return R.sweep_fail;
 #else
   (void)R; (void)ld;
   return nullptr;
@@ -1159,13 +1160,24 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
 
 // every wave on its own, batches pulled from per-sub-strip ticket counters (R.tickets: zeroed here, on the stream);
 // the grid is what is resident: G workgroups per strip, G x strips <= slots (two workgroups per CU the stream may use)
+// Where a pulled sweep's pack kernel runs.  With a side stream (the overlapped loop: R is a ring HALF with a packed-multiplier
+// buffer and ticket counters of its own) it runs there, as soon as the block's decisions are through — normally while the
+// sweep of the block before still streams — and the sweep stream only waits for its event; otherwise in front of the sweep.
+static hipStream_t pack_stream(const FixSide* side, hipStream_t s) { return (side && side->stream && side->packed) ? side->stream : s; }
+static void pack_done(const FixSide* side, hipStream_t s) {
+  if (!(side && side->stream && side->packed)) return;
+  (void)hipEventRecord(side->packed, side->stream);
+  (void)hipStreamWaitEvent(s, side->packed, 0);
+}
+
 static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                              hipStream_t s, int slots = 512) {
+                              hipStream_t s, int slots = 512, const FixSide* side = nullptr) {
   const int nstrips_full = (int)(B.ld / 512);
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, nstrips_full)));
-  hipLaunchKernelGGL(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed,
+  hipLaunchKernelGGL(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, nbt, R.col_packed,
                      R.tickets, nstrips_full * 4, R.clk);
+  pack_done(side, s);
   const dim3 grid(nstrips_full * G), block(256);
 #define LPX_LAUNCH_PULL(NT_, OOP_)                                                                                \
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
@@ -1177,13 +1189,14 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
 
 // blocks of 33..64 by single waves on 64-column sub-strips (k_sweep64_one); G workgroups per group of four sub-strips
 static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                               hipStream_t s, int slots = 512) {
+                               hipStream_t s, int slots = 512, const FixSide* side = nullptr) {
   const int nstrips_full = (int)(B.ld / 512);
   const int ngroups = nstrips_full * 2;
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, ngroups)));
-  hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, s, R.col, R.mp, R.up, kmax, nbt, R.col_packed,
+  hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, nbt, R.col_packed,
                      R.tickets, nstrips_full * 8, R.clk);
+  pack_done(side, s);
   const dim3 grid(ngroups * G), block(256);
 #define LPX_LAUNCH_ONE64(NT_, OOP_)                                                                               \
   hipLaunchKernelGGL((k_sweep64_one<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
@@ -1197,13 +1210,14 @@ static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local
 // blocks of 33..64 on the matrix cores (fused arithmetic only): one wave per SIMD, G workgroups per group of four
 // 64-column sub-strips, 16-row tiles pulled from the sub-strip's ticket counter
 static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                                hipStream_t s, int slots = 256, bool two_waves = false, int kmin = 33) {
+                                hipStream_t s, int slots = 256, bool two_waves = false, int kmin = 33, const FixSide* side = nullptr) {
   const int nstrips_full = (int)(B.ld / 512);
   const int ngroups = nstrips_full * 2;
   const int ntiles = m_local / 16;
   const int G = std::max(1, std::min(ntiles, slots / std::max(1, ngroups)));
-  hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, s, R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
+  hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
                      R.tickets, nstrips_full * 8, R.clk, two_waves ? 1 : 0);
+  pack_done(side, s);
   if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
     const int ng2 = nstrips_full * 4;
     const int G2 = std::max(1, std::min(ntiles, 2 * slots / std::max(1, ng2)));
@@ -1285,14 +1299,10 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
   }
   // The fix-up's chains read ring values only (and b, which the sweep leaves alone): with a side stream they are computed
   // BESIDE the sweep into the images of this ring half, and only their copy into the tableau follows the sweep.
+  // Likewise the pack kernel of a pulled sweep (pack_stream): first on the side stream, then the chains.
   const bool side_fix = side && side->stream && R.fix_col && R.fix_row;
-  if (side_fix) {
-    const int gxf = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
-    (void)hipStreamWaitEvent(side->stream, side->ready, 0);
-    hipLaunchKernelGGL(k_block_fixup, dim3(gxf, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, side->stream, B.A, B.ld, n, m_local, row0,
-                       B.b, R.prow, R.col, R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, (long long*)nullptr, R.fix_col, R.fix_row);
-    (void)hipEventRecord(side->done, side->stream);
-  }
+  if (side_fix) (void)hipStreamWaitEvent(side->stream, side->ready, 0);
+  else side = nullptr;
   if (K <= 16) {
     // tiles of a few rows (k_update_tiles): up to K = 16 the sweep is HBM-bound and 16-row tiles stream best
     // (profiles/r01_sweep_rows.txt: larger tiles widen the set of DRAM pages in flight, -10 %)
@@ -1339,11 +1349,11 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     const bool whole = mfma && mfma2 && B.ld % 512 == 0;
     if (mfma) {
 #if LPX_FUSED
-      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, mfma2, whole ? 1 : 33);
+      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, mfma2, whole ? 1 : 33, side);
 #endif
       rows64 = 16;
     } else if (one) {
-      launch_sweep64_one(B, R, m_local, K, nt, A_src, s, 2 * cus);
+      launch_sweep64_one(B, R, m_local, K, nt, A_src, s, 2 * cus, side);
       rows64 = 4;
     }
 #ifdef LPX_WITH_VARIANTS
@@ -1406,7 +1416,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     }
 #endif
     if (!done && pullable) {
-      launch_sweep_pull(B, R, m_local, K, nt, A_src, s, 2 * cus);
+      launch_sweep_pull(B, R, m_local, K, nt, A_src, s, 2 * cus, side);
       used = kSweepPull;
       if (B.ld % 512 != 0) launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);   // the partial last strip
       rows_per_wg = 4;   // (what lpx_state_get_info reports as the run length: one batch)
@@ -1421,7 +1431,10 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
   // fix-up must not pair its stamp with a front stamp of an older launch (lpx_state_info.sweep_clock_mhz then says 0)
   const bool probed = used == kSweepPull || used == kSweepPull64 || used == kSweepOne64 || used == kSweepMfma64 || used == kSweepMfma642;
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
-  if (side_fix) {   // the chains were computed beside the sweep (launched above): only their copy into the tableau is left
+  if (side_fix) {   // the chains beside the sweep (behind its pack kernel on the side stream); only their copy into the tableau follows it
+    hipLaunchKernelGGL(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, side->stream, B.A, B.ld, n, m_local, row0,
+                       B.b, R.prow, R.col, R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, (long long*)nullptr, R.fix_col, R.fix_row);
+    (void)hipEventRecord(side->done, side->stream);
     (void)hipStreamWaitEvent(s, side->done, 0);
     hipLaunchKernelGGL(k_block_fixup_scatter, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 2), dim3(256), 0, s, B.A, B.ld, m_local, row0,
                        R.fix_col, R.fix_row, R.mp, R.up, K, probed ? R.clk : nullptr);
