@@ -807,11 +807,13 @@ int ensure_overlap_streams(lpx_state* s) {
 // 64 CUs (which have 0.8 ms of every block to spare there) and 700-800 us squeezed in between the sweep's own waves.
 int ensure_fix_side(lpx_state* s, int mode) {
   if (mode < 1 || mode > 3) return fail(LPX_BAD_ARGUMENT, "ensure_fix_side: mode");
+  const size_t K = 2 * lpxk::kBlockMax;
   if (!s->R.fix_col) {
-    const size_t K = 2 * lpxk::kBlockMax;
     HIP_TRY(hipMalloc((void**)&s->R.fix_col, K * (size_t)s->R.mp * sizeof(double)));
-    HIP_TRY(hipMalloc((void**)&s->R.fix_row, K * (size_t)s->B.ld * sizeof(double)));
     HIP_TRY(hipMemsetAsync(s->R.fix_col, 0, K * (size_t)s->R.mp * sizeof(double), s->stream));
+  }
+  if (!s->R.fix_row) {
+    HIP_TRY(hipMalloc((void**)&s->R.fix_row, K * (size_t)s->B.ld * sizeof(double)));
     HIP_TRY(hipMemsetAsync(s->R.fix_row, 0, K * (size_t)s->B.ld * sizeof(double), s->stream));
   }
   for (int k = 0; k < 2; k++) {
@@ -877,8 +879,11 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots, cons
   int64_t decided = 0;
   int nb_prev = 0, nblk = 0;
   const bool serial = s->opt[LPX_OPT_OVERLAP_SERIAL] != 0;
-  const int fix_mode = serial ? 0 : (int)s->opt[LPX_OPT_FIXUP_SIDE];
-  if (fix_mode > 0) if (int rc = ensure_fix_side(s, fix_mode)) return rc;
+  int fix_mode = serial ? 0 : (int)s->opt[LPX_OPT_FIXUP_SIDE];
+  if (fix_mode > 0 && ensure_fix_side(s, fix_mode) != 0) {   // no memory for the images / no third stream: the fix-up
+    (void)hipGetLastError();                                   // stays behind the sweep (same results)
+    fix_mode = 0;
+  }
   // (The decision kernel's private ring copies — identity padding behind a block's last pivot, its start indices — are
   // only meaningful to the kernel FORM that wrote them.  A launch treats the other ring half as pending pivots only for
   // k > 0 of THIS call (n_old = 0 for the first block of every call), and the form is read once per launch from the
