@@ -67,7 +67,7 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
     instruction-issue floor costs the same cycles whatever the clock).  The instruction term of `bound` is taken on the CUs
     the sweep's stream really has (`cus`: lpx_state_info.sweep_cus — in the overlapped loop the decisions keep 4 or 8 CUs
     per XCD to themselves); on the matrix cores (k_sweep64_mfma2: fp64 MFMA rate = fp64 vector rate on MI355X) the name
-    is "fp64_mfma".  `pivot_equiv_frac` keeps SURVEY 8(d)'s per-PIVOT figure (16*m*n bytes per pivot / 8 TB/s), which
+    is "mfma".  `pivot_equiv_frac` keeps SURVEY 8(d)'s per-PIVOT figure (16*m*n bytes per pivot / 8 TB/s), which
     exceeds 1 when one sweep applies several pivots."""
     if not launches or not (avg_ms > 0):
         return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
@@ -82,7 +82,7 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
     ncu = int(cus) if cus and cus > 0 else 256
     t_valu_clk = flops / (ncu * 4 * 16 * (clock_ghz or 2.4) * 1e9)   # on the sweep's CUs, at the clock held
     hbm_peak_bound = t_hbm >= t_valu                  # which data-sheet peak `frac` / `achieved` are quoted against
-    fp64_name = "fp64_mfma" if fused and kernel in MFMA_KERNELS else "fp64_valu"
+    fp64_name = "mfma" if fused and kernel in MFMA_KERNELS else "fp64_valu"   # ("mfma": the fp64 matrix pipe, v_mfma_f64_16x16x4)
     out = {"bound": "hbm" if t_hbm >= t_valu_clk else fp64_name,
            "bound_at": ("measured clock" if clock_ghz else "nominal clock (not measured)") + ", %d CUs" % ncu,
            "cus": ncu,
@@ -106,6 +106,14 @@ def roofline_block(m_local, n, pivots_per_launch, avg_ms, kernel, launches, traf
            "algorithmic_bytes_per_launch": bytes_moved,
            "pivot_equiv_GBps": bytes_moved * pivots_per_launch / t / 1e9,
            "pivot_equiv_frac": bytes_moved * pivots_per_launch / t / 1e9 / HBM_PEAK_GBS}
+    if fp64_name == "mfma":
+        # the same launch against the dense fp64 MFMA peak (a multiply-add = 2 flop; v_mfma_f64_16x16x4 issues in 64 cycles
+        # per SIMD: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz = 78.6 TFLOP/s, the vector peak), and against what its own CUs
+        # give at the clock the chip held — the figure that says how far the kernel is from its binding pipe
+        tf = 2.0 * flops / t / 1e12
+        peak_here = ncu * 4 * 32 * (clock_ghz or 2.4) * 1e9 / 1e12
+        out["mfma"] = {"achieved": tf, "peak": 2.0 * FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / (2.0 * FP64_VALU_PEAK_TFLOPS),
+                       "peak_on_its_cus_at_clock": peak_here, "frac_on_its_cus_at_clock": tf / peak_here}
     return out
 
 

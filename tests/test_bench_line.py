@@ -27,7 +27,7 @@ def test_roofline_block_is_bounded_and_names_the_binding_term():
     # the decisions leave): 16 x 64 cycles per 16 x 16 tile = m n 64 lane-operations on 192 x 4 SIMDs = 1.365 ms > the memory
     # pass (1.074 ms): the matrix pipe binds, although on all 256 CUs it would not (Weak 4)
     rm = bench.roofline_block(32768, 16384, 64, 1.898, "k_sweep64_mfma2", 8, fused=True, clock_mhz=2048, cus=192)
-    assert rm["bound"] == "fp64_mfma" and rm["cus"] == 192 and 1.36 < rm["lower_bound_ms"]["fp64_on_its_cus_at_clock"] < 1.37
+    assert rm["bound"] == "mfma" and rm["cus"] == 192 and 1.36 < rm["lower_bound_ms"]["fp64_on_its_cus_at_clock"] < 1.37
     assert bench.roofline_block(32768, 16384, 64, 1.898, "k_sweep64_mfma2", 8, fused=True, clock_mhz=2048)["bound"] == "hbm"
     # nothing sampled: no fraction is invented
     assert bench.roofline_block(8192, 16384, 32, float("nan"), "k", 0)["frac"] is None
