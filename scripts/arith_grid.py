@@ -32,7 +32,7 @@ for item in items:
             opts[k.strip()] = int(v)
     st = lps.LPState(A, b, c, options=opts)
     st.simplex_loop(max_pivots=warm)
-    st.profile_enable(1)
+    st.profile_enable(int(os.environ.get("GRID_PROFILE_EVERY", "1")))   # HIP events around every n-th sweep launch (0: none)
     t0 = time.perf_counter()
     status, piv, _ = st.simplex_loop(max_pivots=steps)
     dt = time.perf_counter() - t0
