@@ -168,9 +168,7 @@ typedef struct lpx_state_info {
   int32_t multi_onehop;         /* lpx_multi: 1 = the last decision launches used the one-hop exchange              */
   int32_t sweep_clock_mhz;      /* shader clock the chip held over the last pulled sweep launch (k_sweep32_pull, k_sweep64_one,
                                    k_sweep64_mfma2, ...: in-kernel s_memtime against the 100 MHz counter, one pair of stamps per XCD
-                                   in the launches around the sweep — with LPX_OPT_FIXUP_SIDE != 0 the front stamp is taken when the
-                                   block's multipliers are packed, possibly while the sweep before still runs: the mean clock of that
-                                   longer window); 0 = not measured (another sweep kernel ran last) */
+                                   as the sweep starts and in the launch behind it); 0 = not measured (another sweep kernel ran last) */
   int32_t sweep_cus;            /* CUs the stream of the last blocked sweep could use (all of them outside the overlapped loop) */
   int32_t arith_fused;          /* arithmetic in effect (LPX_OPT_FUSED resolved): 0 = two roundings per update, 1 = fused multiply-add */
 } lpx_state_info;

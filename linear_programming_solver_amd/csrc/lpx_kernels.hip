@@ -1056,7 +1056,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
   LPX_EACH_NT_OOP(LPX_PRE_STEADY) LPX_EACH_NT_OOP(LPX_PRE_PIPE) LPX_EACH_NT_OOP(LPX_PRE_DMA)
 #endif
 #define LPX_PRE_PULL(NT_, OOP_) \
-  hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 1, R.col_packed, R.tickets);
+  hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.col, R.mp, R.up, 0, 1, R.col_packed, R.tickets, (long long*)nullptr);
   if (R.tickets && R.col_packed) {   // m_local = 0: the first ticket already names nothing
     LPX_EACH_NT_OOP(LPX_PRE_PULL)
     hipLaunchKernelGGL(k_pack_multipliers<32>, dim3(1), dim3(256), 0, s, R.col, R.mp, R.up, 0, 0, R.col_packed, R.tickets, 0, (long long*)nullptr);
@@ -1068,7 +1068,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
 #undef LPX_PRE_PULL64
 #endif
 #define LPX_PRE_ONE64(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_one<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets);
+    hipLaunchKernelGGL((k_sweep64_one<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, (long long*)nullptr);
     LPX_EACH_NT_OOP(LPX_PRE_ONE64)
 #undef LPX_PRE_ONE64
 #if LPX_FUSED
@@ -1080,7 +1080,7 @@ void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) 
 #undef LPX_PRE_MFMA64
 #endif
 #define LPX_PRE_MFMA642(NT_, OOP_) \
-    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, 33);
+    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), dim3(1), dim3(256), 0, s, A, A, ld, 0, R.prow, R.up, 0, 1, R.col_packed, R.tickets, 33, (long long*)nullptr);
     LPX_EACH_NT_OOP(LPX_PRE_MFMA642)
 #undef LPX_PRE_MFMA642
 #endif
@@ -1176,12 +1176,12 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, nstrips_full)));
   hipLaunchKernelGGL(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, nbt, R.col_packed,
-                     R.tickets, nstrips_full * 4, R.clk);
+                     R.tickets, nstrips_full * 4, (long long*)nullptr);
   pack_done(side, s);
   const dim3 grid(nstrips_full * G), block(256);
 #define LPX_LAUNCH_PULL(NT_, OOP_)                                                                                \
   hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
-                     R.up, kmax, nstrips_full, R.col_packed, R.tickets)
+                     R.up, kmax, nstrips_full, R.col_packed, R.tickets, R.clk)
   if (A_src) { if (nt) LPX_LAUNCH_PULL(true, true); else LPX_LAUNCH_PULL(false, true); }
   else { if (nt) LPX_LAUNCH_PULL(true, false); else LPX_LAUNCH_PULL(false, false); }
 #undef LPX_LAUNCH_PULL
@@ -1195,12 +1195,12 @@ static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, ngroups)));
   hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, nbt, R.col_packed,
-                     R.tickets, nstrips_full * 8, R.clk);
+                     R.tickets, nstrips_full * 8, (long long*)nullptr);
   pack_done(side, s);
   const dim3 grid(ngroups * G), block(256);
 #define LPX_LAUNCH_ONE64(NT_, OOP_)                                                                               \
   hipLaunchKernelGGL((k_sweep64_one<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                     nstrips_full, R.col_packed, R.tickets)
+                     nstrips_full, R.col_packed, R.tickets, R.clk)
   if (A_src) { if (nt) LPX_LAUNCH_ONE64(true, true); else LPX_LAUNCH_ONE64(false, true); }
   else { if (nt) LPX_LAUNCH_ONE64(true, false); else LPX_LAUNCH_ONE64(false, false); }
 #undef LPX_LAUNCH_ONE64
@@ -1216,7 +1216,7 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
   const int ntiles = m_local / 16;
   const int G = std::max(1, std::min(ntiles, slots / std::max(1, ngroups)));
   hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
-                     R.tickets, nstrips_full * 8, R.clk, two_waves ? 1 : 0);
+                     R.tickets, nstrips_full * 8, two_waves ? (long long*)nullptr : R.clk, two_waves ? 1 : 0);
   pack_done(side, s);
   if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
     const int ng2 = nstrips_full * 4;
@@ -1224,7 +1224,7 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
     const dim3 grid2(ng2 * G2), block2(256);
 #define LPX_LAUNCH_MFMA642(NT_, OOP_)                                                                               \
     hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), grid2, block2, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                       nstrips_full, R.col_packed, R.tickets, kmin)
+                       nstrips_full, R.col_packed, R.tickets, kmin, R.clk)
     if (A_src) { if (nt) LPX_LAUNCH_MFMA642(true, true); else LPX_LAUNCH_MFMA642(false, true); }
     else { if (nt) LPX_LAUNCH_MFMA642(true, false); else LPX_LAUNCH_MFMA642(false, false); }
 #undef LPX_LAUNCH_MFMA642
@@ -1427,7 +1427,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
   }
   if (kernel_used) *kernel_used = used;
   if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
-  // the clock probe: only the pack kernels of the pulled sweeps stamp in FRONT of a sweep; behind any other form the
+  // the clock probe: only the pulled sweeps stamp at their START (sweep_front_stamp; the variants' through their pack kernels); behind any other form the
   // fix-up must not pair its stamp with a front stamp of an older launch (lpx_state_info.sweep_clock_mhz then says 0)
   const bool probed = used == kSweepPull || used == kSweepPull64 || used == kSweepOne64 || used == kSweepMfma64 || used == kSweepMfma642;
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
