@@ -50,9 +50,9 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 }
 int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
                        int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
-                       hipStream_t s, const MgPeers* mg) {
+                       hipStream_t s, const MgPeers* mg, hipEvent_t stop) {
   return LPX_PICK(B, launch_block_chain)(B, R, n, m, nb, half, old_half, n_old, b_from_tableau, seq, dantzig, wgs, fences, trace,
-                                  host_snap, s, mg);
+                                  host_snap, s, mg, stop);
 }
 // both sets: the arithmetic mode is an option of the handle and may be set after its ring has been built
 void preload_block_kernels(const Buffers& B, const BlockRing& R, hipStream_t s) {
@@ -66,9 +66,9 @@ int chain_blocks_per_cu() { return std::min(plain::chain_blocks_per_cu(), fused:
 const char* sweep_kernel_name(int code) { return plain::sweep_kernel_name(code); }
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep, int cus,
-                       int form, int* kernel_used, const FixSide* side) {
+                       int form, int* kernel_used, const FixSide* side, hipEvent_t stop) {
   return LPX_PICK(B, launch_block_sweep)(B, R, n, m_local, row0, K, rows_per_wg, nt, s, A_src, b_src, after_sweep, cus,
-                                         form, kernel_used, side);
+                                         form, kernel_used, side, stop);
 }
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {
   plain::launch_fill_column(A, ld, m, col, value, s);

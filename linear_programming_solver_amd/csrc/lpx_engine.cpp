@@ -686,7 +686,7 @@ int device_cus(const lpx_state* s) {
 
 // B / R: destination buffers and the ring half of the block; A_src / b_src != NULL: out of place
 int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers& B, const lpxk::BlockRing& R,
-                                 const double* A_src, const double* b_src, const lpxk::FixSide* side) {
+                                 const double* A_src, const double* b_src, const lpxk::FixSide* side, hipEvent_t stop) {
   const bool sample = s->prof > 0 && (s->prof_seq++ % s->prof) == 0;
   if (sample) {
     if (s->ev_used + 2 > s->ev.size()) {
@@ -705,14 +705,14 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
   s->info.sweep_rows = lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, (int)s->opt[LPX_OPT_SWEEP_ROWS],
                                                 s->nontemporal, stream, A_src, b_src,
                                                 sample ? s->ev[s->ev_used + 1] : nullptr, cus,
-                                                (int)s->opt[LPX_OPT_SWEEP_FORM], &kernel_used, side);
+                                                (int)s->opt[LPX_OPT_SWEEP_FORM], &kernel_used, side, stop);
   s->info.sweep_kernel = kernel_used;
   if (sample) s->ev_used += 2;
   HIP_TRY(hipGetLastError());
   return 0;
 }
 static int launch_sweep_profiled(lpx_state* s, int K) {
-  return launch_sweep_profiled(s, K, s->stream, s->B, s->R, nullptr, nullptr, nullptr);
+  return launch_sweep_profiled(s, K, s->stream, s->B, s->R, nullptr, nullptr, nullptr, nullptr);
 }
 
 // Ring half h as a ring of its own (what the sweep / fix-up kernels take).
@@ -898,17 +898,18 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots, cons
       Brd.A = Abuf[h];
       Brd.b = bbuf[h];
       s->info.chain_wgs = lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, 0, 1, s->chain_seq++, s->pricing == 1,
-                                                   chain_wgs, fences, trace, d_snap + h, s->ov_chain);
+                                                   chain_wgs, fences, trace, d_snap + h, s->ov_chain, nullptr, s->ev_ov_chain[h]);
     } else {
       if (k >= 2) HIP_TRY(hipStreamWaitEvent(s->ov_chain, s->ev_ov_sweep[h], 0));  // sweep k-2
       Brd.A = Abuf[k == 0 ? 0 : (k - 1) & 1];
       Brd.b = bbuf[k == 0 ? 0 : (k - 1) & 1];
       s->info.chain_wgs = lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0,
                                                    s->chain_seq++, s->pricing == 1, chain_wgs, fences, trace, d_snap + h,
-                                                   s->ov_chain);
+                                                   s->ov_chain, nullptr, s->ev_ov_chain[h]);
     }
     s->chain_nb_last = nb;
-    HIP_TRY(hipEventRecord(s->ev_ov_chain[h], s->ov_chain));
+    // (ev_ov_chain[h] is the launch's own stop event: an event recorded behind it would be a queue packet of its own between
+    // this decision launch and the next, 4.7 us beside the sweep — scripts/micro/launch_gap.hip)
     if (max_pivots >= 0 && decided == max_pivots) {  // the budget is spent: this decision can only report the end
       decided += nb;                                 // (LIMIT / UNBOUNDED), there is nothing to sweep
       return 0;
@@ -923,8 +924,8 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots, cons
     // The sweep's pack kernel goes the same way, in front of the chains: its multiplier buffer and ticket counters are the
     // ring half's own, free since sweep k-2.
     const lpxk::FixSide side{fix_mode > 0 ? s->ov_fix[fix_mode] : nullptr, s->ev_ov_chain[h], s->ev_ov_fix[h], s->ev_ov_pack[h]};
-    if (int rc = launch_sweep_profiled(s, nb, s->ov_sweep, Bdst, ring_half(s, h), Abuf[h], bbuf[h], fix_mode > 0 ? &side : nullptr)) return rc;
-    HIP_TRY(hipEventRecord(s->ev_ov_sweep[h], s->ov_sweep));
+    if (int rc = launch_sweep_profiled(s, nb, s->ov_sweep, Bdst, ring_half(s, h), Abuf[h], bbuf[h], fix_mode > 0 ? &side : nullptr,
+                                       s->ev_ov_sweep[h])) return rc;   // (likewise the stop event of the block's last kernel)
     decided += nb;
     nb_prev = nb;
     nblk = k + 1;

@@ -111,7 +111,8 @@ int block_len(int K, int64_t max_pivots, int64_t decided);
 int clamp_chain_wgs(lpx_state* s, int want, int cus);
 int device_cus(const lpx_state* s);
 int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers& B, const lpxk::BlockRing& R,
-                          const double* A_src, const double* b_src, const lpxk::FixSide* side = nullptr);
+                          const double* A_src, const double* b_src, const lpxk::FixSide* side = nullptr,
+                          hipEvent_t stop = nullptr);   // stop: signalled when everything the call enqueued on `stream` is through
 int ensure_fix_side(lpx_state* s, int mode);   // ov_fix[mode], ev_ov_fix and the ring's images (R.fix_col / R.fix_row)
 lpxk::BlockRing ring_half(const lpx_state* s, int h);
 void launch_seed_entering(lpx_state* s, const lpxk::LoopStart& start = lpxk::LoopStart{});   // start.reset: also starts the loop state over

@@ -24,6 +24,8 @@
 // (or splitting) anything on its own.
 #include "lpx_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <atomic>
 
 #include <limits.h>
@@ -810,6 +812,16 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+// A launch that also signals `stop_` (may be NULL) when the kernel is through.  hipExtLaunchKernelGGL attaches the event to
+// the kernel's own completion signal: an event RECORDED behind a launch is a packet of its own on the queue and costs the
+// next launch of the stream 2.9 us alone and 4.7 us beside a kernel that streams through HBM; attached it costs nothing
+// (scripts/micro/launch_gap.hip, profiles/r05_launch_gap.txt).
+#define LPX_LAUNCH_STOP(kernel_, grid_, block_, stream_, stop_, ...)                                        \
+  do {                                                                                                      \
+    hipEvent_t lpx_stop_ = (stop_);                                                                          \
+    if (lpx_stop_) hipExtLaunchKernelGGL(kernel_, grid_, block_, 0, stream_, nullptr, lpx_stop_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel_, grid_, block_, 0, stream_, __VA_ARGS__);                               \
+  } while (0)
 void launch_entering(const Buffers& B, int n, hipStream_t s, const LoopStart& start) {
   hipLaunchKernelGGL(k_entering, dim3(1), dim3(1024), 0, s, B.c, n, B.ctl, start);
 }
@@ -922,7 +934,7 @@ void launch_block_decide(const Buffers& B, const BlockRing& R, int n, int m_glob
 // alternate); B.A / B.b: the tableau version to read.
 int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int nb, int half, int old_half, int n_old,
                         int b_from_tableau, int seq, int dantzig, int wgs, int fences, bool trace, LpxCtl* host_snap,
-                        hipStream_t s, const MgPeers* mg) {
+                        hipStream_t s, const MgPeers* mg, hipEvent_t stop) {
   // fences = 2 (the engine's default), acquire only: everything that crosses workgroups inside the launch is stored
   // write-through (st_agent = sc1), every storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets, ONE lane
   // arrives with an agent-scope atomic add, the poller's loads of the handed-off bytes are all sc1 loads (ld_agent)
@@ -984,24 +996,27 @@ int launch_block_chain(const Buffers& B, const BlockRing& R, int n, int m, int n
       P.arrive2_peer[d] = mg->arrive2[d];
     }
     if (form2) {
-      if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, true>), dim3(G), dim3(kChain2Threads), 0, s, P);
-      else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, true>), dim3(G), dim3(kChain2Threads), 0, s, P);
-    } else hipLaunchKernelGGL((k_block_chain_t<true, 32>), dim3(G), dim3(256), 0, s, P);   // (shards decide at most kShardBlockMax = 32 per block)
+      if (wide) LPX_LAUNCH_STOP((k_block_chain2_t<64, kChain2Threads, true>), dim3(G), dim3(kChain2Threads), s, stop, P);
+      else LPX_LAUNCH_STOP((k_block_chain2_t<32, kChain2Threads, true>), dim3(G), dim3(kChain2Threads), s, stop, P);
+    } else LPX_LAUNCH_STOP((k_block_chain_t<true, 32>), dim3(G), dim3(256), s, stop, P);   // (shards decide at most kShardBlockMax = 32 per block)
   } else if (form2) {
     P.m_global = m; P.n_dev = 1;
 #ifdef LPX_CHAIN2_ONE_XCD
     G = std::min(G, 32);
     if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, false>), dim3(8 * G), dim3(kChain2Threads), 0, s, P);
     else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, false>), dim3(8 * G), dim3(kChain2Threads), 0, s, P);
+    if (stop) (void)hipEventRecord(stop, s);
 #else
-    if (wide) hipLaunchKernelGGL((k_block_chain2_t<64, kChain2Threads, false>), dim3(G), dim3(kChain2Threads), 0, s, P);
-    else hipLaunchKernelGGL((k_block_chain2_t<32, kChain2Threads, false>), dim3(G), dim3(kChain2Threads), 0, s, P);
+    if (wide) LPX_LAUNCH_STOP((k_block_chain2_t<64, kChain2Threads, false>), dim3(G), dim3(kChain2Threads), s, stop, P);
+    else LPX_LAUNCH_STOP((k_block_chain2_t<32, kChain2Threads, false>), dim3(G), dim3(kChain2Threads), s, stop, P);
 #endif
   } else {
 #ifdef LPX_WITH_VARIANTS
     P.m_global = m; P.n_dev = 1;
-    if (wide) hipLaunchKernelGGL((k_block_chain_t<false, 64>), dim3(G), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL((k_block_chain_t<false, 32>), dim3(G), dim3(256), 0, s, P);
+    if (wide) LPX_LAUNCH_STOP((k_block_chain_t<false, 64>), dim3(G), dim3(256), s, stop, P);
+    else LPX_LAUNCH_STOP((k_block_chain_t<false, 32>), dim3(G), dim3(256), s, stop, P);
+#else
+    if (stop) (void)hipEventRecord(stop, s);
 #endif
   }
   return G;
@@ -1164,10 +1179,9 @@ static void launch_sweep_k(const Buffers& B, const BlockRing& R, int m_local, in
 // buffer and ticket counters of its own) it runs there, as soon as the block's decisions are through — normally while the
 // sweep of the block before still streams — and the sweep stream only waits for its event; otherwise in front of the sweep.
 static hipStream_t pack_stream(const FixSide* side, hipStream_t s) { return (side && side->stream && side->packed) ? side->stream : s; }
-static void pack_done(const FixSide* side, hipStream_t s) {
-  if (!(side && side->stream && side->packed)) return;
-  (void)hipEventRecord(side->packed, side->stream);
-  (void)hipStreamWaitEvent(s, side->packed, 0);
+static hipEvent_t pack_stop(const FixSide* side) { return (side && side->stream && side->packed) ? side->packed : nullptr; }
+static void pack_done(const FixSide* side, hipStream_t s) {   // (the event is the pack launch's own stop event)
+  if (pack_stop(side)) (void)hipStreamWaitEvent(s, side->packed, 0);
 }
 
 static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
@@ -1175,7 +1189,7 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
   const int nstrips_full = (int)(B.ld / 512);
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, nstrips_full)));
-  hipLaunchKernelGGL(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, nbt, R.col_packed,
+  LPX_LAUNCH_STOP(k_pack_multipliers<32>, dim3((nbt + 7) / 8), dim3(256), pack_stream(side, s), pack_stop(side), R.col, R.mp, R.up, kmax, nbt, R.col_packed,
                      R.tickets, nstrips_full * 4, (long long*)nullptr);
   pack_done(side, s);
   const dim3 grid(nstrips_full * G), block(256);
@@ -1194,7 +1208,7 @@ static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local
   const int ngroups = nstrips_full * 2;
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, ngroups)));
-  hipLaunchKernelGGL(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, nbt, R.col_packed,
+  LPX_LAUNCH_STOP(k_pack_multipliers<64>, dim3((nbt + 3) / 4), dim3(256), pack_stream(side, s), pack_stop(side), R.col, R.mp, R.up, kmax, nbt, R.col_packed,
                      R.tickets, nstrips_full * 8, (long long*)nullptr);
   pack_done(side, s);
   const dim3 grid(ngroups * G), block(256);
@@ -1215,7 +1229,7 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
   const int ngroups = nstrips_full * 2;
   const int ntiles = m_local / 16;
   const int G = std::max(1, std::min(ntiles, slots / std::max(1, ngroups)));
-  hipLaunchKernelGGL(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), 0, pack_stream(side, s), R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
+  LPX_LAUNCH_STOP(k_pack_multipliers_mfma, dim3(ntiles), dim3(256), pack_stream(side, s), pack_stop(side), R.col, R.mp, R.up, kmax, ntiles, R.col_packed,
                      R.tickets, nstrips_full * 8, two_waves ? (long long*)nullptr : R.clk, two_waves ? 1 : 0);
   pack_done(side, s);
   if (two_waves) {   // k_sweep64_mfma2: groups of 128 columns, two workgroups per CU
@@ -1288,10 +1302,10 @@ const char* sweep_kernel_name(int code) {
 // rows_per_wg <= 0: chosen here (see choose_sweep_rows); cus: CUs the stream may use (0: the whole device)
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep,
-                       int cus, int form, int* kernel_used, const FixSide* side) {
+                       int cus, int form, int* kernel_used, const FixSide* side, hipEvent_t stop) {
   int used = kSweepNone;
   if (kernel_used) *kernel_used = used;
-  if (K < 1) return 0;
+  if (K < 1) { if (stop) (void)hipEventRecord(stop, s); return 0; }
   if (cus <= 0) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1432,17 +1446,24 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
   const bool probed = used == kSweepPull || used == kSweepPull64 || used == kSweepOne64 || used == kSweepMfma64 || used == kSweepMfma642;
   const int gx = (int)((std::max<int64_t>(m_local, B.ld) + 255) / 256);
   if (side_fix) {   // the chains beside the sweep (behind its pack kernel on the side stream); only their copy into the tableau follows it
-    hipLaunchKernelGGL(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, side->stream, B.A, B.ld, n, m_local, row0,
-                       B.b, R.prow, R.col, R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, (long long*)nullptr, R.fix_col, R.fix_row);
-    (void)hipEventRecord(side->done, side->stream);
+    LPX_LAUNCH_STOP(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), side->stream, side->done, B.A, B.ld, n, m_local, row0,
+                    B.b, R.prow, R.col, R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, (long long*)nullptr, R.fix_col, R.fix_row);
     (void)hipStreamWaitEvent(s, side->done, 0);
-    hipLaunchKernelGGL(k_block_fixup_scatter, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 2), dim3(256), 0, s, B.A, B.ld, m_local, row0,
-                       R.fix_col, R.fix_row, R.mp, R.up, K, probed ? R.clk : nullptr);
-  } else {
-    hipLaunchKernelGGL(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), 0, s, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
-                       R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, probed ? R.clk : nullptr, nullptr, nullptr);
   }
-  if (!probed && R.clk) (void)hipMemsetAsync(R.clk, 0, 256, s);
+  // `stop` (the caller's "this block's sweep is through"): the stop event of the last kernel — unless the probe's memset follows
+  const bool memset_behind = !probed && R.clk;
+  hipEvent_t last_stop = memset_behind ? nullptr : stop;
+  if (side_fix) {
+    LPX_LAUNCH_STOP(k_block_fixup_scatter, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 2), dim3(256), s, last_stop, B.A, B.ld, m_local, row0,
+                    (const double*)R.fix_col, (const double*)R.fix_row, R.mp, R.up, K, probed ? R.clk : (long long*)nullptr);
+  } else {
+    LPX_LAUNCH_STOP(k_block_fixup, dim3(gx, (K + kFixChunk - 1) / kFixChunk, 3), dim3(256), s, last_stop, B.A, B.ld, n, m_local, row0, B.b, R.prow, R.col,
+                    R.col0, R.row0, R.mp, R.up, K, b_src ? b_src : B.b, probed ? R.clk : (long long*)nullptr, (double*)nullptr, (double*)nullptr);
+  }
+  if (memset_behind) {
+    (void)hipMemsetAsync(R.clk, 0, 256, s);
+    if (stop) (void)hipEventRecord(stop, s);
+  }
   return rows_per_wg;
 }
 

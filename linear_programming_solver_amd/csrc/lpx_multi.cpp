@@ -310,10 +310,9 @@ static int multi_loop_overlapped(lpx_multi* M, int K, int64_t max_pivots, int wa
       lpxk::MgPeers P = peers_of(M, r);
       P.mail_slot0 = (int)(decided & 1);
       lpxk::launch_block_chain(Brd, s->R, s->n, s->m, nb, h, h ^ 1, k > 0 ? nb_prev : 0, k == 0, M->seq, dantzig, wgs,
-                               fences, trace, M->d_snap[r] + h, s->ov_chain, &P);
+                               fences, trace, M->d_snap[r] + h, s->ov_chain, &P, s->ev_ov_chain[h]);   // (its own stop event)
       s->chain_nb_last = nb;
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(s->ev_ov_chain[h], s->ov_chain));
     }
     M->seq++;
     if (!probe_only) {
@@ -325,9 +324,8 @@ static int multi_loop_overlapped(lpx_multi* M, int K, int64_t max_pivots, int wa
         Bdst.A = h ? Abuf0[r] : Abuf1[r];   // buffer h -> buffer h ^ 1
         Bdst.b = h ? bbuf0[r] : bbuf1[r];
         if (int rc = launch_sweep_profiled(s, nb, s->ov_sweep, Bdst, ring_half(s, h), h ? Abuf1[r] : Abuf0[r],
-                                           h ? bbuf1[r] : bbuf0[r]))
+                                           h ? bbuf1[r] : bbuf0[r], nullptr, s->ev_ov_sweep[h]))
           return rc;
-        HIP_TRY(hipEventRecord(s->ev_ov_sweep[h], s->ov_sweep));
       }
       nb_prev = nb;
       nblk = k + 1;
