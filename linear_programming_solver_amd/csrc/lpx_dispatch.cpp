@@ -66,9 +66,9 @@ int chain_blocks_per_cu() { return std::min(plain::chain_blocks_per_cu(), fused:
 const char* sweep_kernel_name(int code) { return plain::sweep_kernel_name(code); }
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep, int cus,
-                       int form, int* kernel_used, const FixSide* side, hipEvent_t stop) {
+                       int form, int* kernel_used, const FixSide* side, hipEvent_t stop, hipEvent_t before_sweep) {
   return LPX_PICK(B, launch_block_sweep)(B, R, n, m_local, row0, K, rows_per_wg, nt, s, A_src, b_src, after_sweep, cus,
-                                         form, kernel_used, side, stop);
+                                         form, kernel_used, side, stop, before_sweep);
 }
 void launch_fill_column(double* A, int64_t ld, int m, int col, double value, hipStream_t s) {
   plain::launch_fill_column(A, ld, m, col, value, s);

@@ -696,7 +696,6 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
         s->ev.push_back(e);
       }
     }
-    HIP_TRY(hipEventRecord(s->ev[s->ev_used], stream));
   }
   // CUs the sweep's stream may use: all but the decisions' reserved ones on the masked overlap stream
   const int cus = (stream == s->ov_sweep && s->ov_masked) ? s->ov_sweep_cus : device_cus(s);
@@ -705,7 +704,8 @@ int launch_sweep_profiled(lpx_state* s, int K, hipStream_t stream, const Buffers
   s->info.sweep_rows = lpxk::launch_block_sweep(B, R, s->n, s->m, s->row0, K, (int)s->opt[LPX_OPT_SWEEP_ROWS],
                                                 s->nontemporal, stream, A_src, b_src,
                                                 sample ? s->ev[s->ev_used + 1] : nullptr, cus,
-                                                (int)s->opt[LPX_OPT_SWEEP_FORM], &kernel_used, side, stop);
+                                                (int)s->opt[LPX_OPT_SWEEP_FORM], &kernel_used, side, stop,
+                                                sample ? s->ev[s->ev_used] : nullptr);
   s->info.sweep_kernel = kernel_used;
   if (sample) s->ev_used += 2;
   HIP_TRY(hipGetLastError());

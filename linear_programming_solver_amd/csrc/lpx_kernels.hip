@@ -822,6 +822,13 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ A,
     if (lpx_stop_) hipExtLaunchKernelGGL(kernel_, grid_, block_, 0, stream_, nullptr, lpx_stop_, 0, __VA_ARGS__); \
     else hipLaunchKernelGGL(kernel_, grid_, block_, 0, stream_, __VA_ARGS__);                               \
   } while (0)
+// ... and one that is timed by a pair of events of its own (profiling of the sweeps: the kernel's duration, nothing around it)
+#define LPX_LAUNCH_TIMED(kernel_, grid_, block_, stream_, t0_, t1_, ...)                                    \
+  do {                                                                                                      \
+    hipEvent_t lpx_t0_ = (t0_), lpx_t1_ = (t1_);                                                             \
+    if (lpx_t0_ && lpx_t1_) hipExtLaunchKernelGGL(kernel_, grid_, block_, 0, stream_, lpx_t0_, lpx_t1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel_, grid_, block_, 0, stream_, __VA_ARGS__);                               \
+  } while (0)
 void launch_entering(const Buffers& B, int n, hipStream_t s, const LoopStart& start) {
   hipLaunchKernelGGL(k_entering, dim3(1), dim3(1024), 0, s, B.c, n, B.ctl, start);
 }
@@ -1185,7 +1192,8 @@ static void pack_done(const FixSide* side, hipStream_t s) {   // (the event is t
 }
 
 static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                              hipStream_t s, int slots = 512, const FixSide* side = nullptr) {
+                              hipStream_t s, int slots = 512, const FixSide* side = nullptr, hipEvent_t t0 = nullptr,
+                              hipEvent_t t1 = nullptr) {
   const int nstrips_full = (int)(B.ld / 512);
   const int nbt = m_local / 4;
   const int G = std::max(1, std::min(nbt, slots / std::max(1, nstrips_full)));
@@ -1194,8 +1202,8 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
   pack_done(side, s);
   const dim3 grid(nstrips_full * G), block(256);
 #define LPX_LAUNCH_PULL(NT_, OOP_)                                                                                \
-  hipLaunchKernelGGL((k_sweep32_pull<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
-                     R.up, kmax, nstrips_full, R.col_packed, R.tickets, R.clk)
+  LPX_LAUNCH_TIMED((k_sweep32_pull<NT_, OOP_>), grid, block, s, t0, t1, B.A, A_src, B.ld, m_local, R.prow, R.col, R.mp, \
+                   R.up, kmax, nstrips_full, R.col_packed, R.tickets, R.clk)
   if (A_src) { if (nt) LPX_LAUNCH_PULL(true, true); else LPX_LAUNCH_PULL(false, true); }
   else { if (nt) LPX_LAUNCH_PULL(true, false); else LPX_LAUNCH_PULL(false, false); }
 #undef LPX_LAUNCH_PULL
@@ -1203,7 +1211,8 @@ static void launch_sweep_pull(const Buffers& B, const BlockRing& R, int m_local,
 
 // blocks of 33..64 by single waves on 64-column sub-strips (k_sweep64_one); G workgroups per group of four sub-strips
 static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                               hipStream_t s, int slots = 512, const FixSide* side = nullptr) {
+                               hipStream_t s, int slots = 512, const FixSide* side = nullptr, hipEvent_t t0 = nullptr,
+                               hipEvent_t t1 = nullptr) {
   const int nstrips_full = (int)(B.ld / 512);
   const int ngroups = nstrips_full * 2;
   const int nbt = m_local / 4;
@@ -1213,8 +1222,8 @@ static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local
   pack_done(side, s);
   const dim3 grid(ngroups * G), block(256);
 #define LPX_LAUNCH_ONE64(NT_, OOP_)                                                                               \
-  hipLaunchKernelGGL((k_sweep64_one<NT_, OOP_>), grid, block, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                     nstrips_full, R.col_packed, R.tickets, R.clk)
+  LPX_LAUNCH_TIMED((k_sweep64_one<NT_, OOP_>), grid, block, s, t0, t1, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
+                   nstrips_full, R.col_packed, R.tickets, R.clk)
   if (A_src) { if (nt) LPX_LAUNCH_ONE64(true, true); else LPX_LAUNCH_ONE64(false, true); }
   else { if (nt) LPX_LAUNCH_ONE64(true, false); else LPX_LAUNCH_ONE64(false, false); }
 #undef LPX_LAUNCH_ONE64
@@ -1224,7 +1233,8 @@ static void launch_sweep64_one(const Buffers& B, const BlockRing& R, int m_local
 // blocks of 33..64 on the matrix cores (fused arithmetic only): one wave per SIMD, G workgroups per group of four
 // 64-column sub-strips, 16-row tiles pulled from the sub-strip's ticket counter
 static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_local, int kmax, bool nt, const double* A_src,
-                                hipStream_t s, int slots = 256, bool two_waves = false, int kmin = 33, const FixSide* side = nullptr) {
+                                hipStream_t s, int slots = 256, bool two_waves = false, int kmin = 33, const FixSide* side = nullptr,
+                                hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
   const int nstrips_full = (int)(B.ld / 512);
   const int ngroups = nstrips_full * 2;
   const int ntiles = m_local / 16;
@@ -1237,8 +1247,8 @@ static void launch_sweep64_mfma(const Buffers& B, const BlockRing& R, int m_loca
     const int G2 = std::max(1, std::min(ntiles, 2 * slots / std::max(1, ng2)));
     const dim3 grid2(ng2 * G2), block2(256);
 #define LPX_LAUNCH_MFMA642(NT_, OOP_)                                                                               \
-    hipLaunchKernelGGL((k_sweep64_mfma2<NT_, OOP_>), grid2, block2, 0, s, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
-                       nstrips_full, R.col_packed, R.tickets, kmin, R.clk)
+    LPX_LAUNCH_TIMED((k_sweep64_mfma2<NT_, OOP_>), grid2, block2, s, t0, t1, B.A, A_src, B.ld, m_local, R.prow, R.up, kmax, \
+                     nstrips_full, R.col_packed, R.tickets, kmin, R.clk)
     if (A_src) { if (nt) LPX_LAUNCH_MFMA642(true, true); else LPX_LAUNCH_MFMA642(false, true); }
     else { if (nt) LPX_LAUNCH_MFMA642(true, false); else LPX_LAUNCH_MFMA642(false, false); }
 #undef LPX_LAUNCH_MFMA642
@@ -1302,10 +1312,19 @@ const char* sweep_kernel_name(int code) {
 // rows_per_wg <= 0: chosen here (see choose_sweep_rows); cus: CUs the stream may use (0: the whole device)
 int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local, int row0, int K, int rows_per_wg,
                        bool nt, hipStream_t s, const double* A_src, const double* b_src, hipEvent_t after_sweep,
-                       int cus, int form, int* kernel_used, const FixSide* side, hipEvent_t stop) {
+                       int cus, int form, int* kernel_used, const FixSide* side, hipEvent_t stop, hipEvent_t before_sweep) {
   int used = kSweepNone;
   if (kernel_used) *kernel_used = used;
-  if (K < 1) { if (stop) (void)hipEventRecord(stop, s); return 0; }
+  if (K < 1) {
+    if (before_sweep) (void)hipEventRecord(before_sweep, s);
+    if (after_sweep) (void)hipEventRecord(after_sweep, s);
+    if (stop) (void)hipEventRecord(stop, s);
+    return 0;
+  }
+  // profiling (before_sweep / after_sweep): ONE pulled sweep kernel takes the pair as its own start / stop events (its duration,
+  // no packet on the queue); any other form is bracketed by two recorded events
+  bool timed_own = false, bracket_open = false;
+  auto bracket = [&]() { if (before_sweep && !bracket_open) { (void)hipEventRecord(before_sweep, s); bracket_open = true; } };
   if (cus <= 0) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1320,6 +1339,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
   if (K <= 16) {
     // tiles of a few rows (k_update_tiles): up to K = 16 the sweep is HBM-bound and 16-row tiles stream best
     // (profiles/r01_sweep_rows.txt: larger tiles widen the set of DRAM pages in flight, -10 %)
+    bracket();
     int rows_per_tile = rows_per_wg <= 0 ? 16 : rows_per_wg;
     rows_per_tile = std::max(8, std::min(rows_per_tile, kSweepMaxRows)) & ~7;  // rows go four or eight at a time
     while (rows_per_tile > 8 && (int64_t)rows_per_tile * B.ld * 8 >= (int64_t)1 << 32) rows_per_tile -= 8;  // 32-bit offsets
@@ -1361,9 +1381,12 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     // the matrix-core sweep over whole strips takes ANY number of valid pivots: no generic launches behind it (they cost
     // two launches and their gaps per block, ~20 us of a 2.1 ms block at cfg4, only to find nothing to do)
     const bool whole = mfma && mfma2 && B.ld % 512 == 0;
+    timed_own = whole && before_sweep && after_sweep;
+    if (!timed_own) bracket();
     if (mfma) {
 #if LPX_FUSED
-      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, mfma2, whole ? 1 : 33, side);
+      launch_sweep64_mfma(B, R, m_local, K, nt, A_src, s, cus, mfma2, whole ? 1 : 33, side, timed_own ? before_sweep : nullptr,
+                          timed_own ? after_sweep : nullptr);
 #endif
       rows64 = 16;
     } else if (one) {
@@ -1395,6 +1418,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     // a partly filled block of 17..31 pivots (the tail of a pivot budget) where the pulled kernel does not apply: the tile
     // kernel's guarded path took such blocks faster than the long-run kernel's (cfg3, 20 pivots, same box: 490 vs 615 us);
     // 64-row tiles as long as the grid keeps a few thousand workgroups (profiles/r01_sweep_rows.txt)
+    bracket();
     const int64_t nstrips = (B.ld + 511) / 512;
     int rows_per_tile = 16;
     for (int rows : {64, 32})
@@ -1414,7 +1438,14 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     const bool pullable = m_local % 4 == 0 && B.ld >= 512 && !wide32 && R.zeros && R.tickets && R.col_packed;
     bool done = false;
 #ifdef LPX_WITH_VARIANTS
-    if (m_local % 4 == 0 && B.ld >= 512 && (form == 1 || form == 2 || !pullable)) {
+    const bool variant32 = m_local % 4 == 0 && B.ld >= 512 && (form == 1 || form == 2 || !pullable);
+#else
+    const bool variant32 = false;
+#endif
+    timed_own = !variant32 && pullable && B.ld % 512 == 0 && before_sweep && after_sweep;   // k_sweep32_pull alone
+    if (!timed_own) bracket();
+#ifdef LPX_WITH_VARIANTS
+    if (variant32) {
       int rows48 = choose_pipe_rows(m_local, (int)(B.ld / 512), 2 * cus, 48);
       while (rows48 > 4 && (int64_t)rows48 * B.ld * 8 >= (int64_t)1 << 32) rows48 -= 4;   // 32-bit offsets
       if (form == 2 && pullable) {   // LDS-DMA staging, runs of rows (the step between the two)
@@ -1430,7 +1461,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     }
 #endif
     if (!done && pullable) {
-      launch_sweep_pull(B, R, m_local, K, nt, A_src, s, 2 * cus, side);
+      launch_sweep_pull(B, R, m_local, K, nt, A_src, s, 2 * cus, side, timed_own ? before_sweep : nullptr, timed_own ? after_sweep : nullptr);
       used = kSweepPull;
       if (B.ld % 512 != 0) launch_sweep_k<32>(B, R, m_local, K, rows_per_wg, nt, A_src, s, 1);   // the partial last strip
       rows_per_wg = 4;   // (what lpx_state_get_info reports as the run length: one batch)
@@ -1440,7 +1471,7 @@ int launch_block_sweep(const Buffers& B, const BlockRing& R, int n, int m_local,
     }
   }
   if (kernel_used) *kernel_used = used;
-  if (after_sweep) (void)hipEventRecord(after_sweep, s);  // profiling: the sweep kernel alone
+  if (after_sweep && !timed_own) { bracket(); (void)hipEventRecord(after_sweep, s); }  // profiling: the sweep kernels alone
   // the clock probe: only the pulled sweeps stamp at their START (sweep_front_stamp; the variants' through their pack kernels); behind any other form the
   // fix-up must not pair its stamp with a front stamp of an older launch (lpx_state_info.sweep_clock_mhz then says 0)
   const bool probed = used == kSweepPull || used == kSweepPull64 || used == kSweepOne64 || used == kSweepMfma64 || used == kSweepMfma642;
