@@ -633,23 +633,30 @@ int choose_block(const lpx_state* s) {
   int K = (int)s->opt[LPX_OPT_BLOCK];
   if (K == 0) {
     const double sweep_us = 16.0 * (double)s->m * (double)s->B.ld / 6.0e6;
-    // measured with the round-3 decision grid (scripts/block_policy.py, profiles/r03_block_policy.txt), pivots/s:
-    // 16 MiB two-launch 71.1k vs K = 16 69.7k; 20 MiB 66.2k vs 69.2k; 32 MiB 56.7k vs 70.0k;
-    // 256 MiB K = 16 67.2k vs K = 32 65.8k; 384-448 MiB equal; 512 MiB 59.6k vs 63.2k; 1 GiB K = 32 50.6k vs 32.8k
-    if (sweep_us < 6.3) K = 1;         // up to ~18 MiB: the two-launch loop wins
-    else if (sweep_us < 115.0) K = 16; // up to ~330 MiB (round 4, with k_block_chain2: 384 MiB 70.4k pivots/s with 32 against
-                                        // 67.1-68.1k with 16, 256 MiB a tie; profiles/r04_block_by_size_small.txt)
+    // Re-measured with the round-5 decision kernel and launches (profiles/r05_block_policy_{small,mid}_sizes.txt,
+    // r05_block_policy_64_and_tiny.txt; same box, 2048 pivots, pivots/s).  A block costs ~17 us besides its decisions (~12 us
+    // from the end of one decision launch to the entry of the next, 4-6 us of prologue: profiles/r05_chain_launch_stamps.txt),
+    // so longer blocks win as soon as the ladder of pending pivots is cheap enough:
+    //   two launches per pivot against blocks of 16: 256 x 512 58-62k vs 99k, 1024 x 2048 (16 MiB) 50k vs 96k — blocks win
+    //     at EVERY size once their ring exists; but building the ring (buffers, streams, one preparing launch of every
+    //     kernel) takes ~24 ms, what ~2 400 pivots of a small tableau save, and a tableau of a few hundred rows is solved
+    //     in fewer: below ~18 MiB a handle that has no ring yet keeps the two-launch loop, one that has takes blocks of 16;
+    //   16 against 32: 1024 x 2048 95.8k / 95.0k, 1536 x 2048 (24 MiB) 95.0k / 94.2k, 2048 x 2048 (32 MiB) 92.9k / 94.7k,
+    //     2048 x 4096 93.8k / 96.1k, 4096 x 4096 88.2k / 91.2k, 4096 x 8192 (256 MiB) 85.9k / 89.5k, 6144 x 6144 85.2k / 88.6k;
+    //   32 against 64 (plain: k_sweep64_one): 4096 x 8192 89.5k / 80.0k.
+    if (sweep_us < 6.3) K = s->R.prow ? 16 : 1;
+    else if (sweep_us < 10.0) K = 16;   // up to ~28 MiB
     else K = 32;
     // 64: the two-stage sweep moves half the bytes per pivot and takes 0.74x the time per pivot alone on the chip, but
     // 64-slot decisions cost twice as much each (their ring reads grow with K^2) and take bandwidth from the sweep
     // beside them: +3..5 % over 32 from 4 GiB to 12 GiB tableaux (profiles/r02_block64_policy.txt), -22 % at 2 GiB.
     // By size only from ~7 GiB up (8 GiB +4.3 %, 12 GiB +5.4 %), where the kernel applies; opt-in below.
     if (sweep_us >= 2500.0 && s->m % 4 == 0 && s->B.ld >= 512) K = 64;
-    // fused arithmetic: blocks of 33..64 run on the matrix cores (k_sweep64_mfma2, 16-row tiles) and pay from ~1.1 GiB
-    // (profiles/r04_block_by_size_fused.txt, same box, pivots/s with blocks of 64 / 32: 1.125 GiB 54.3k / 52.5k, 1.25 GiB
-    // 53.0k / 48.0k, 1.5 GiB 50.3-52.4k / 38.1-42.7k, cfg4 27.5k / 18.2k; 1 GiB — cfg3 — 54.0-55.0k / 54.9-55.3k: a tie,
-    // blocks of 32 there; 0.5 GiB 57-60k / 67-70k)
-    if (s->B.fused && sweep_us >= 380.0 && s->m % 16 == 0 && s->B.ld >= 512 && s->m_global == s->m) K = 64;
+    // fused arithmetic: blocks of 33..64 run on the matrix cores (k_sweep64_mfma2, 16-row tiles).  Round 5, blocks of 32 / 64:
+    // 0.5 GiB (8192 x 8192) 86.8k / 81.8k, 0.625 GiB 84.9k / 79.6k, 0.75 GiB 79.8k / 77.9k (four shapes, all for 32),
+    // 0.875 GiB (8192 x 14336) 73.3k / 75.7k, 1 GiB (cfg3) 67.7k / 73.7k; round 4 above: 1.25 GiB 48.0k / 53.0k,
+    // cfg4 18.2k / 27.5k (profiles/r04_block_by_size_fused.txt).  From ~0.85 GiB.
+    if (s->B.fused && sweep_us >= 300.0 && s->m % 16 == 0 && s->B.ld >= 512 && s->m_global == s->m) K = 64;
   }
   // three launches per decision (option chain = 0, the form the shards use): its kernels hold at most 32 pending pivots
   if (!s->opt[LPX_OPT_CHAIN] || s->m_global != s->m) K = std::min(K, (int)lpxk::kShardBlockMax);
@@ -1142,6 +1149,13 @@ extern "C" int lpx_debug_read_census(lpx_state* s, uint32_t* out, int32_t count)
   if (!s || !out || !s->R.census || count < 0 || count > (int)lpxk::kChainMaxWgs + 2 + 1200) return LPX_BAD_ARGUMENT;
   if (hipSetDevice(s->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return LPX_DEVICE_ERROR;
   return hipMemcpy(out, s->R.census, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : LPX_DEVICE_ERROR;
+}
+
+// diagnostic builds (LPX_CHAIN2_LAUNCH_STAMPS): raw copy of the decision kernel's stamp buffer (16 x kBlockMax words)
+extern "C" int lpx_debug_read_chain_dbg(lpx_state* s, int64_t* out, int32_t count) {
+  if (!s || !out || !s->R.chain_dbg || count < 0 || count > 16 * (int)lpxk::kBlockMax) return LPX_BAD_ARGUMENT;
+  if (hipSetDevice(s->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return LPX_DEVICE_ERROR;
+  return hipMemcpy(out, s->R.chain_dbg, (size_t)count * sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess ? 0 : LPX_DEVICE_ERROR;
 }
 
 // stamps per decision the decision kernel of this handle writes: k_block_chain_t 5, k_block_chain2_t 8

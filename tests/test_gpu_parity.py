@@ -874,11 +874,12 @@ def _timed_form_vs_oracle(lps, oracle, m, n, budgets, options=None, threads=16):
     return info
 
 
-def test_cfg3_timed_form_200_pivots_vs_fp64_oracle(lps, oracle):
-    """BASELINE cfg3 (8192 x 16384): 70 + 200 pivots through the default loop — full K = 32 blocks, the wide
-    decision kernel beside the sweeps, a budget tail folded into the last block."""
+def test_cfg3_timed_form_200_pivots_vs_fp64_oracle(lps, oracle, arith):
+    """BASELINE cfg3 (8192 x 16384): 70 + 200 pivots through the default loop — full blocks (32 pivots; 64 on the matrix
+    cores in the fused arithmetic, by size from ~0.85 GiB since round 5), the wide decision kernel beside the sweeps, a
+    budget tail folded into the last block."""
     info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (70, 200))
-    assert info["block"] == 32 and info["overlapped"] == 1
+    assert info["block"] == (64 if arith == "fused" else 32) and info["overlapped"] == 1
     assert info["chain_wgs"] <= info["chain_resident_max"]
     if info["chain_stream_masked"]:   # by size: 8 CUs per XCD for the decisions, one column per thread (workgroup 0 + 63)
         assert info["chain_resident_max"] == 64 and info["chain_wgs"] == 64, info
@@ -931,7 +932,7 @@ def test_cfg3_sweep_of_blocks_of_32_vs_fp64_oracle(lps, oracle):
     order) through two full blocks and a tail at cfg3 (a short one, which the tile kernel takes, then one of 28 pivots, which
     it takes padded with identity steps), against the fp64 oracle.  (The kernels it replaced — sweep_form 1 / 2 — are checked
     the same way in tests/test_gpu_variants.py, on the variants library.)"""
-    info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (75, 60), options={"sweep_form": 0})
+    info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (75, 60), options={"sweep_form": 0, "block": 32})
     assert info["block"] == 32 and info["sweep_kernel_name"] == "k_sweep32_pull"
 
 
@@ -992,12 +993,13 @@ def test_wide_decision_kernel_vs_oracle(lps, oracle, shape, fences, block):
     st.close()
 
 
-@pytest.mark.parametrize("shape,block,wgs", [((1024, 2048), 1, None), ((1280, 2048), 16, 9), ((2048, 4096), 16, 17),
-                                             ((4096, 8192), 16, 32), ((6144, 8192), 32, 32), ((8192, 8192), 32, 32)])
+@pytest.mark.parametrize("shape,block,wgs", [((1024, 2048), 1, None), ((1280, 2048), 16, 9), ((2048, 4096), 32, 17),
+                                             ((4096, 8192), 32, 32), ((6144, 8192), 32, 32), ((8192, 8192), 32, 32)])
 def test_block_and_decision_grid_by_size(lps, oracle, shape, block, wgs):
-    """The by-size choices of the default loop (profiles/r03_block_policy.txt, r03_decision_grid.txt): one pass per pivot
-    up to ~18 MiB, blocks of 16 up to ~330 MiB (round 4: profiles/r04_block_by_size_small.txt), 32 above; the decision kernel with one row / column per thread (+ the
-    workgroup of the hand-off window), within the 32 CUs of its masked stream.  150 pivots against the fp64 oracle."""
+    """The by-size choices of the default loop (round 5: profiles/r05_block_policy_*.txt; r03_decision_grid.txt): one pass per
+    pivot up to ~18 MiB on a handle without a ring, blocks of 16 up to ~28 MiB, 32 above; the decision kernel with one row /
+    column per thread (+ the workgroup of the hand-off window), within the 32 CUs of its masked stream.  150 pivots against
+    the fp64 oracle."""
     m, n = shape
     A, b, c = dense_lp(m, n, seed=m + 7 * n)
     st = lps.LPState(A, b, c)

@@ -56,7 +56,7 @@ def oracle(arith):
 def test_cfg3_superseded_sweeps_of_blocks_of_32_vs_fp64_oracle(lps, oracle, form, name):
     """Round 2's register-staged sweep and round 3's LDS-DMA sweep with runs of rows, each through two full blocks and a tail
     at cfg3 against the oracle of the arithmetic mode."""
-    info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (75, 60), options={"sweep_form": form})
+    info = _timed_form_vs_oracle(lps, oracle, 8192, 16384, (75, 60), options={"sweep_form": form, "block": 32})
     assert info["block"] == 32 and info["sweep_kernel_name"] == name
 
 
