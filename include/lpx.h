@@ -124,7 +124,7 @@ int lpx_pivot(lpx_state* s, int32_t entering, int32_t leaving);
  * only supply the initial values (debugging aid for the scripts/ helpers).  Setting an option between two loops
  * is allowed; inside a loop nothing reads them.  Unknown key / value out of range -> LPX_BAD_ARGUMENT. */
 typedef enum lpx_option {
-  LPX_OPT_BLOCK = 0,          /* pivots per sweep: 0 = by size, 1 = off, 2..64 (same as lpx_state_set_block)        */
+  LPX_OPT_BLOCK = 0,          /* pivots per sweep: 0 = by size (1 below ~18 MiB of tableau on a handle without a ring, 16 up to ~28 MiB, 32 up to ~7 GiB, 64 above; fused arithmetic: 64 from ~0.85 GiB), 1 = off, 2..64 (same as lpx_state_set_block) */
   LPX_OPT_CHAIN = 1,          /* 1 = all decisions of a block in one persistent launch (default); 0 = three launches */
   LPX_OPT_OVERLAP = 2,        /* 1 = decisions of block k+1 beside the sweep of block k (default); 0 = serial        */
   LPX_OPT_OVERLAP_SERIAL = 3, /* 1 = the overlapped loop's kernels and buffers without concurrency (diagnostics)     */
