@@ -144,7 +144,7 @@ typedef enum lpx_option {
   LPX_OPT_CHAIN_CUS = 17,     /* overlapped loop: CUs per XCD reserved for the decision kernel (4, 8, 12 or 16; other values are rounded down to a multiple of 4 but never below 4; 0 = by size: 8 for decision-bound tableaus above 8192 rows or columns, else 4); set before the first blocked loop: LPX_BAD_ARGUMENT once the handle's stream pair exists */
   LPX_OPT_FUSED = 18,         /* arithmetic of the updates x - c*r (LPState.java:162, :164, :177) and v + b*c (:171): 0 = product and difference rounded separately, as the reference rounds them (bit-identical to the unfused fp64 oracle); 1 = one fused multiply-add each (bit-identical to the oracle's fused instantiation); 2 (default) = by size: fused on an unsharded tableau of 0.5 GiB and more, where it is 5-75 % faster, otherwise 0.  Both binary modes leave the decimal-15 pivot sequence of the reference equally often (tests/golden/divergence_census.json).  lpx_state_info.arith_fused reports the mode in effect.  Every kernel of the handle switches together; set it before the first pivot of a solve (the two modes give different bits, so a switch in mid-solve matches neither checker) */
   LPX_OPT_CHAIN_FORM = 19,    /* decision kernel of the blocked loop: 0 = k_block_chain_t (round 2/3), 1 (default) = k_block_chain2_t (round 4/5: a phase asks for everything at once, nothing is drained on the critical path, branch-free pending-pivot ladder; workgroups of 256 threads; also on the shards of an lpx_multi unless LPX_OPT_MULTI_ONEHOP is set) */
-  LPX_OPT_FIXUP_SIDE = 20,    /* overlapped loop: where the fix-up of a block (its entering columns and pivot rows recomputed from the ring, LPState.java:139-164) runs.  0 = behind the block's sweep, writing the tableau; 2 (default) = its chains BESIDE the sweep on a stream with the decisions' CU mask, into compact images, and only the copy of those images (k_block_fixup_scatter) behind the sweep; 1 = likewise on the sweep's CUs; 3 = likewise without a mask.  Unsharded handles only (the shards of an lpx_multi keep 0).  Same values, same order per entry: bit-identical results in every setting */
+  LPX_OPT_FIXUP_SIDE = 20,    /* overlapped loop: where the fix-up of a block (its entering columns and pivot rows recomputed from the ring, LPState.java:139-164) runs.  0 = behind the block's sweep, writing the tableau; 2 = its chains (and the sweep's pack kernel) BESIDE the sweep on a stream with the decisions' CU mask, into compact images, and only the copy of those images (k_block_fixup_scatter) behind the sweep; 1 = likewise on the sweep's CUs; 3 = likewise without a mask; 4 (default) = by size: 2 from 2 GiB of tableau, where the sweep sets the pace, 0 below, where the decisions do.  Unsharded handles only (the shards of an lpx_multi keep 0).  Same values, same order per entry: bit-identical results in every setting */
   LPX_OPT_COUNT = 21
 } lpx_option;
 int lpx_state_set_option(lpx_state* s, int32_t key, int64_t value);

@@ -80,7 +80,7 @@ static const OptionSpec kOptionSpec[LPX_OPT_COUNT] = {
     {"LPX_CHAIN_CUS", 0, 0, 16},            // LPX_OPT_CHAIN_CUS
     {"LPX_FUSED", 2, 0, 2},                 // LPX_OPT_FUSED
     {"LPX_CHAIN_FORM", 1, 0, 1},            // LPX_OPT_CHAIN_FORM
-    {"LPX_FIXUP_SIDE", 2, 0, 3},            // LPX_OPT_FIXUP_SIDE
+    {"LPX_FIXUP_SIDE", 4, 0, 4},            // LPX_OPT_FIXUP_SIDE
 };
 
 static const int64_t* env_defaults() {
@@ -887,6 +887,11 @@ static int blocked_loop_overlapped(lpx_state* s, int K, int64_t max_pivots, cons
   int nb_prev = 0, nblk = 0;
   const bool serial = s->opt[LPX_OPT_OVERLAP_SERIAL] != 0;
   int fix_mode = serial ? 0 : (int)s->opt[LPX_OPT_FIXUP_SIDE];
+  // 4 = by size: beside the sweep on the decisions' CUs where the SWEEP sets the pace and the decisions have time to spare
+  // (cfg4: +1.2 %); behind the sweep where the decisions set it — there anything that shares their CUs costs them more than the
+  // sweep stream's idle time is worth (same box, behind / beside: 2048 x 4096 100.2k / 98.0k pivots/s, 4096 x 8192 93.6k / 91.1k,
+  // 8192 x 8192 88.5k / 86.3k, cfg3 74.2k / 73.5k; profiles/r05_fixup_side_decision_bound.txt)
+  if (fix_mode == 4) fix_mode = 8.0 * (double)s->m * (double)s->B.ld >= 2.0 * 1073741824.0 ? 2 : 0;
   if (fix_mode > 0 && ensure_fix_side(s, fix_mode) != 0) {   // no memory for the images / no third stream: the fix-up
     (void)hipGetLastError();                                   // stays behind the sweep (same results)
     fix_mode = 0;

@@ -898,12 +898,13 @@ def test_decision_cus_option_vs_fp64_oracle(lps, oracle, cus, resident):
         assert info["chain_resident_max"] == resident and info["chain_wgs"] in (min(48, resident), min(49, resident)), info
 
 
-@pytest.mark.parametrize("side", [0, 1, 2, 3])
+@pytest.mark.parametrize("side", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("shape,block", [((4096, 12288), 32), ((2048, 4096), 64), ((1000, 1500), 64)])
 def test_fixup_beside_or_behind_the_sweep_vs_oracle(lps, oracle, shape, block, side):
     """Option fixup_side (LPX_OPT_FIXUP_SIDE): the entering columns and pivot rows of a block recomputed from the ring
     (LPState.java:139-164) behind the block's sweep (0) or beside it into images that only a copy kernel takes into the
-    tableau afterwards (1: on the sweep's CUs, 2: the decisions' CUs — the default —, 3: no mask).  Three full blocks and
+    tableau afterwards (1: on the sweep's CUs, 2: the decisions' CUs, 3: no mask; 4, the default: by size — 2 from 2 GiB, the
+    cfg4 tests, 0 below).  Three full blocks and
     tails (a second call continues on the swapped buffers) against the oracle of the arithmetic mode, bit for bit; the
     1000 x 1500 case has partial strips and rows that are not a multiple of 4 (generic sweep kernels)."""
     m, n = shape
