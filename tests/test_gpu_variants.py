@@ -112,3 +112,19 @@ def test_round3_decision_kernel_on_one_device(lps, oracle):
         assert (status, pivots) == (want["status"], want["pivots"]), budget
         assert_state_bits_equal(st.read(), ref.read(), "chain_form 0, budget %d" % budget)
     st.close()
+
+
+def test_sweep_of_128_pivots_matches_two_passes_of_64_bit_for_bit():
+    """k_sweep128_mfma (csrc/variants/: a block of up to 128 pivots in one pass on the matrix cores, EXPERIMENTS 000.55) is not
+    reachable through the C ABI yet; `make variants` builds scripts/micro/sweep_mfma128.hip, which runs it on a synthetic ring
+    with 128 / 100 / 64 / 40 valid pivots and compares every entry with two passes of the product's k_sweep64_mfma2 (whose bits
+    the tests of tests/test_gpu_parity.py pin to the oracle's 64 sequential fused updates, LPState.java:162).  Exit code 0 = no
+    entry differs."""
+    import subprocess
+    exe = os.path.join(ROOT, "gpurun_variants", "sweep_mfma128")
+    if not os.path.exists(exe):
+        pytest.skip("gpurun_variants/sweep_mfma128 is not built (make -C linear_programming_solver_amd/csrc variants)")
+    out = subprocess.run([exe, "1024", "1024", "2", "32", "2"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("np ")]
+    assert len(lines) == 4 and all(ln.rstrip().endswith("entries that differ: 0") for ln in lines), out.stdout
