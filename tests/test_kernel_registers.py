@@ -329,3 +329,63 @@ def test_mfma_sweep_loop_never_drains_its_memory_queue(device_asm_fused):
         # 41 = the hand-written wait in front of a ticket's take (one step's 16 + 8 loads, 16 stores and the next pull are
         # younger than the atomic); everything else is the compiler's, clamped
         assert waits.count(41) == 3 and all(w == 41 or w >= 62 for w in waits), (name, sorted(set(waits)))
+
+
+@pytest.fixture(scope="module")
+def device_asm_sweep128(tmp_path_factory):
+    """scripts/micro/sweep_mfma128.hip (fused compilation + csrc/variants/): the only translation unit that instantiates
+    k_sweep128_mfma until the engine dispatches to it."""
+    if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("asm128") / "sweep_mfma128.s"
+    subprocess.check_call([HIPCC if os.path.exists(HIPCC) else "hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-ffp-contract=off", "-Wno-unused-result", "-DLPX_FUSED=1", "-DLPX_WITH_VARIANTS",
+                           "-I", os.path.dirname(SRC), "-S", "--cuda-device-only",
+                           os.path.join(ROOT, "scripts", "micro", "sweep_mfma128.hip"), "-o", str(out)], stderr=subprocess.DEVNULL)
+    return out.read_text()
+
+
+def test_sweep_of_128_pivots_loop_as_designed(device_asm_sweep128):
+    """k_sweep128_mfma (csrc/variants/, EXPERIMENTS 000.55): two workgroups per CU (<= 256 registers, <= 80 KiB of LDS, no
+    scratch) and a tile loop as hand-counted: straight-line, two tiles of 128 MFMAs per round, per tile 16 + 16 loads, 16
+    stores and ONE hand-issued ticket atomic, whose take waits behind exactly what was issued after it (vmcnt(49) = 32 loads +
+    16 stores + the next pull); no other wait of the loop is stricter than a step's own operations (>= 48: the compiler's waits
+    for the tile loaded a step earlier)."""
+    asm = device_asm_sweep128
+    res = _resources(asm, "k_sweep128_mfma")
+    assert len(res) >= 1, "k_sweep128_mfma is not instantiated"
+    for name, r in res.items():
+        assert r["private_seg_size"] == 0 and r["num_vgpr"] + r["num_agpr"] <= 256, (name, r)
+    lds = re.findall(r"\.amdhsa_group_segment_fixed_size (\d+)", "".join(
+        asm[m.start():m.start() + 4000] for m in re.finditer(r"\.amdhsa_kernel \S*k_sweep128_mfma", asm)))
+    assert lds and all(int(x) <= 80 * 1024 for x in lds), lds
+    for name, lines in _kernel_functions(asm, "k_sweep128_mfma").items():
+        lines = [ln for ln in lines if ln and not ln.startswith(";")]
+        back = [k for k, ln in enumerate(lines) if re.match(r"s_cbranch_scc[01] \.LBB\d+_\d+", ln)]
+        labels = {m.group(1): k for k, ln in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", ln)] if m}
+        loops = [(labels[ln.split()[-1]], k) for k in back for ln in [lines[k]] if labels.get(ln.split()[-1], k) < k]
+        assert loops, name
+        head, tail = max(loops, key=lambda ht: sum(1 for ln in lines[ht[0]:ht[1]] if ln.startswith("v_mfma_f64_16x16x4")))
+        body = lines[head:tail]
+        assert sum(1 for ln in body if ln.startswith("v_mfma_f64_16x16x4")) == 256, name
+        assert sum(1 for ln in body if ln.startswith("global_atomic_add")) == 2, name
+        assert not any(ln.startswith(("s_cbranch", "s_branch", "s_barrier")) for ln in body), name
+        assert sum(1 for ln in body if ln.startswith("buffer_load_dwordx2")) == 32, name      # two tiles of C
+        assert sum(1 for ln in body if ln.startswith("buffer_load_dwordx4")) == 32, name      # two tiles of A operands
+        assert sum(1 for ln in body if ln.startswith("buffer_store_dwordx2")) == 32, name
+        assert not any(ln.startswith(("global_load", "global_store", "flat_", "scratch_", "v_lshl_add_u64")) for ln in body), name
+        # the order of the memory operations: pull, take (vmcnt(49)), 32 loads, the tile's arithmetic, 16 stores — twice
+        seq = []
+        for ln in body:
+            if ln.startswith("global_atomic_add"):
+                seq.append("A")
+            elif ln.startswith("buffer_load"):
+                seq.append("L")
+            elif ln.startswith("buffer_store"):
+                seq.append("S")
+        assert "".join(seq) == ("A" + "L" * 32 + "S" * 16) * 2, (name, "".join(seq))
+        waits = [int(x) for ln in body for x in re.findall(r"vmcnt\((\d+)\)", ln)]
+        assert waits.count(49) >= 2 and min(waits) >= 48, (name, sorted(set(waits)))
+        first_wait_after_atomic = [next(int(re.findall(r"vmcnt\((\d+)\)", ln2)[0]) for ln2 in body[k:] if "vmcnt(" in ln2)
+                                   for k, ln in enumerate(body) if ln.startswith("global_atomic_add")]
+        assert first_wait_after_atomic == [49, 49], (name, first_wait_after_atomic)
